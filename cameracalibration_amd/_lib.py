@@ -1,0 +1,86 @@
+"""ctypes binding of libcamcal.so (include/camcal.h).
+
+The product path has exactly one implementation: the HIP library built from
+``csrc/camcal_kernels.hip``.  :func:`load` raises if it is missing -- there is
+no CPU fallback.  Tests may pass an explicit ``path`` (the CPU lane emulator
+under ``tests/hostemu``) to exercise the host logic without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "csrc", "libcamcal.so")
+
+PINHOLE, FISHEYE = 0, 1
+
+
+class Tiles(C.Structure):
+    """struct camcal_tiles (include/camcal.h)."""
+    _fields_ = [("pts", C.c_void_p), ("tile_off", C.c_void_p), ("tile_nmax", C.c_void_p),
+                ("lane_n", C.c_void_p), ("n_tiles", C.c_int32), ("n_slots", C.c_int64)]
+
+
+_P, _I, _D = C.c_void_p, C.c_int, C.c_double
+_TP = C.POINTER(Tiles)
+
+_SIGNATURES = {
+    "camcal_version": (C.c_int, []),
+    "camcal_n_intr": (C.c_int, [_I]),
+    "camcal_glob_len": (C.c_int, [_I]),
+    "camcal_schur_len": (C.c_int, [_I]),
+    "camcal_scratch_len": (C.c_int64, [_I]),
+    "camcal_pack_tiles": (C.c_int, [_P, _P, _P, _P, _TP, _P, _P]),
+    "camcal_pose_init": (C.c_int, [_I, _TP, _P, _P, _P, _P]),
+    "camcal_pose_refine": (C.c_int, [_I, _TP, _P, _P, _I, _D, _P, _P]),
+    "camcal_intr_normal": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P]),
+    "camcal_view_blocks": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P]),
+    "camcal_schur": (C.c_int, [_I, _TP, _P, _P, _P, _D, _P, _P, _P]),
+    "camcal_solve_reduced": (C.c_int, [_I, _P, _P, C.c_char_p, _D, _D, _P, _P, _P, _P, _P]),
+    "camcal_backsub": (C.c_int, [_I, _TP, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
+    "camcal_normal_eq": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
+    "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
+                                    C.POINTER(C.c_float)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class CamcalError(RuntimeError):
+    pass
+
+
+class CamcalLib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise CamcalError(
+                f"{path} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        self.is_emulator = self.camcal_version() < 0
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise CamcalError(f"{what} failed with status {rc}"
+                              + (" (hipError_t)" if rc > 0 else " (CAMCAL_E_*)"))
+
+
+_cached = None
+
+
+def load(path: str | None = None) -> CamcalLib:
+    """Open the HIP library (cached).  ``path`` overrides for tests only."""
+    global _cached
+    if path is not None:
+        return CamcalLib(path)
+    if _cached is None:
+        _cached = CamcalLib(DEFAULT_PATH)
+    return _cached

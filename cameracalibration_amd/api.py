@@ -1,0 +1,282 @@
+"""Drop-in replacements for the two cv2 entry points the reference calls.
+
+* :func:`calibrateCamera`      <- ``cv2.calibrateCamera``
+  (reference: server/aruco/camera_calib.py:153-156,
+  server/internal/IntrinsicCalibration/intrinsicCalib.py:194-197,223-226)
+* :func:`fisheye_calibrate`    <- ``cv2.fisheye.calibrate``
+  (reference: server/aruco/camera_calib.py:74-77,
+  server/internal/IntrinsicCalibration/intrinsicCalib.py:102-105,131-134)
+
+Same positional/keyword signature, same return tuple
+``(retval, cameraMatrix, distCoeffs, rvecs, tvecs)``, K / D written in place
+when the caller passes float64 arrays of the right shape (cv2 InputOutputArray
+semantics), rvecs / tvecs returned as tuples of (3, 1) float64 arrays, invalid
+input raises :class:`error` (cv2.error's stand-in).
+
+Every number is computed by the HIP library; importing this module without the
+built extension or calling it without a ROCm device raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import Engine
+from . import solver as _solver
+
+DBL_EPSILON = float(np.finfo(np.float64).eps)
+
+# --- constants (cv2 4.10 values) -------------------------------
+TERM_CRITERIA_COUNT = 1
+TERM_CRITERIA_MAX_ITER = 1
+TERM_CRITERIA_EPS = 2
+CALIB_USE_INTRINSIC_GUESS = 1
+CALIB_FIX_ASPECT_RATIO = 2
+CALIB_FIX_PRINCIPAL_POINT = 4
+CALIB_ZERO_TANGENT_DIST = 8
+CALIB_FIX_FOCAL_LENGTH = 16
+CALIB_FIX_K1 = 32
+CALIB_FIX_K2 = 64
+CALIB_FIX_K3 = 128
+CALIB_FIX_K4 = 2048
+CALIB_FIX_K5 = 4096
+CALIB_FIX_K6 = 8192
+CALIB_RATIONAL_MODEL = 16384
+CALIB_THIN_PRISM_MODEL = 32768
+CALIB_FIX_S1_S2_S3_S4 = 65536
+CALIB_TILTED_MODEL = 262144
+CALIB_FIX_TAUX_TAUY = 524288
+CALIB_FIX_TANGENT_DIST = 2097152
+
+FISHEYE_CALIB_USE_INTRINSIC_GUESS = 1
+FISHEYE_CALIB_RECOMPUTE_EXTRINSIC = 2
+FISHEYE_CALIB_CHECK_COND = 4
+FISHEYE_CALIB_FIX_SKEW = 8
+FISHEYE_CALIB_FIX_K1 = 16
+FISHEYE_CALIB_FIX_K2 = 32
+FISHEYE_CALIB_FIX_K3 = 64
+FISHEYE_CALIB_FIX_K4 = 128
+FISHEYE_CALIB_FIX_INTRINSIC = 256
+FISHEYE_CALIB_FIX_PRINCIPAL_POINT = 512
+FISHEYE_CALIB_ZERO_DISPARITY = 1024
+FISHEYE_CALIB_FIX_FOCAL_LENGTH = 2048
+
+
+class error(Exception):
+    """Raised where cv2 would raise ``cv2.error``."""
+
+
+_default_device = None
+
+
+def set_device(device):
+    """Select the GPU the drop-in calls run on (default: current cuda device)."""
+    global _default_device
+    _default_device = None if device is None else torch.device(device)
+
+
+def _device():
+    if _default_device is not None:
+        return _default_device
+    if not torch.cuda.is_available():
+        raise _lib.CamcalError("no ROCm device visible: cameracalibration_amd has no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _gather_views(object_points, image_points):
+    """cv2-style lists of (n_i,1,3)/(n_i,1,2) arrays -> CSR float32 arrays."""
+    try:
+        nv = len(object_points)
+        ni = len(image_points)
+    except TypeError:
+        raise error("objectPoints / imagePoints must be sequences of arrays")
+    if nv == 0 or nv != ni:
+        raise error("objectPoints and imagePoints must be non-empty and of equal length "
+                    "(nimages > 0 && nimages == (int)imagePoints.total())")
+    objs, imgs, counts = [], [], []
+    for o, i in zip(object_points, image_points):
+        o = np.asarray(o)
+        i = np.asarray(i)
+        if o.size % 3 or i.size % 2:
+            raise error("objectPoints must be Nx3 / imagePoints Nx2")
+        o = o.reshape(-1, 3).astype(np.float32, copy=False)
+        i = i.reshape(-1, 2).astype(np.float32, copy=False)
+        if o.shape[0] != i.shape[0]:
+            raise error("number of object and image points must be equal in every view")
+        if o.shape[0] < 4:
+            raise error("every view needs at least 4 points")
+        objs.append(o)
+        imgs.append(i)
+        counts.append(o.shape[0])
+    view_ptr = np.zeros(nv + 1, dtype=np.int64)
+    view_ptr[1:] = np.cumsum(counts)
+    obj = np.concatenate(objs, axis=0)
+    img = np.concatenate(imgs, axis=0)
+    if np.any(obj[:, 2] != 0.0):
+        raise error("only planar calibration targets with Z = 0 are supported "
+                    "(the reference's chessboard / ChArUco boards)")
+    return view_ptr, obj, img
+
+
+def _write_back(dst, values):
+    """cv2 InputOutputArray: write into the caller's array when it is a
+    float64 ndarray of matching size, and return the array handed back."""
+    values = np.asarray(values, dtype=np.float64)
+    if isinstance(dst, np.ndarray) and dst.dtype == np.float64 and dst.size == values.size \
+            and dst.flags.writeable:
+        dst[...] = values.reshape(dst.shape)
+        return dst
+    return values
+
+
+def _poses_to_tuples(poses):
+    rvecs = tuple(np.ascontiguousarray(p[:3].reshape(3, 1)) for p in poses)
+    tvecs = tuple(np.ascontiguousarray(p[3:].reshape(3, 1)) for p in poses)
+    return rvecs, tvecs
+
+
+def _pinhole_mask(flags, nd):
+    mask = np.ones(9, dtype=bool)
+    if flags & CALIB_FIX_FOCAL_LENGTH:
+        mask[0] = mask[1] = False
+    if flags & CALIB_FIX_PRINCIPAL_POINT:
+        mask[2] = mask[3] = False
+    if flags & (CALIB_ZERO_TANGENT_DIST | CALIB_FIX_TANGENT_DIST):
+        mask[6] = mask[7] = False
+    if flags & CALIB_FIX_K1:
+        mask[4] = False
+    if flags & CALIB_FIX_K2:
+        mask[5] = False
+    if flags & CALIB_FIX_K3 or nd < 5:
+        mask[8] = False
+    return mask
+
+
+def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs=None,
+                    tvecs=None, flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON),
+                    *, _lib_override=None, _device_override=None, _comm=None, _info=None):
+    """``cv2.calibrateCamera`` on the MI355X (5-coefficient pinhole model).
+
+    Supported: ``CALIB_USE_INTRINSIC_GUESS`` (required -- the only mode the
+    reference uses) optionally with FIX_FOCAL_LENGTH / FIX_PRINCIPAL_POINT /
+    ZERO_TANGENT_DIST / FIX_TANGENT_DIST / FIX_K1..K3.  Other model flags raise.
+    """
+    flags = int(flags)
+    unsupported = (CALIB_FIX_ASPECT_RATIO | CALIB_RATIONAL_MODEL | CALIB_THIN_PRISM_MODEL |
+                   CALIB_TILTED_MODEL)
+    if flags & unsupported:
+        raise error("RATIONAL / THIN_PRISM / TILTED models and FIX_ASPECT_RATIO are not supported")
+    if not flags & CALIB_USE_INTRINSIC_GUESS:
+        raise error("CALIB_USE_INTRINSIC_GUESS is required (cameraMatrix / distCoeffs must hold the guess)")
+    if cameraMatrix is None or distCoeffs is None:
+        raise error("CALIB_USE_INTRINSIC_GUESS needs cameraMatrix and distCoeffs")
+    K = np.asarray(cameraMatrix, dtype=np.float64)
+    D = np.asarray(distCoeffs, dtype=np.float64)
+    if K.shape != (3, 3):
+        raise error("cameraMatrix must be 3x3")
+    if D.size not in (4, 5):
+        raise error("distCoeffs must hold 4 or 5 coefficients")
+    w, h = int(imageSize[0]), int(imageSize[1])
+    if w <= 0 or h <= 0:
+        raise error("image width and height must be positive")
+    if K[0, 0] <= 0 or K[1, 1] <= 0:
+        raise error("Focal length (fx and fy) must be positive")
+    if K[0, 2] < 0 or K[0, 2] >= w or K[1, 2] < 0 or K[1, 2] >= h:
+        raise error("Principal point must be within the image")
+    if abs(K[0, 1]) > 1e-5:
+        raise error("Non-zero skew is not supported by the function")
+    if abs(K[1, 0]) > 1e-5 or abs(K[2, 0]) > 1e-5 or abs(K[2, 1]) > 1e-5 or abs(K[2, 2] - 1) > 1e-5:
+        raise error("The intrinsic matrix must have [fx 0 cx; 0 fy cy; 0 0 1] shape")
+    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
+    dist = np.zeros(5)
+    dist[:D.size] = D.ravel()
+    if flags & CALIB_ZERO_TANGENT_DIST:
+        dist[2] = dist[3] = 0.0
+    mask = _pinhole_mask(flags, D.size)
+    ctype, maxc, eps = criteria
+    if not ctype & TERM_CRITERIA_COUNT:
+        maxc = 1000
+    if not ctype & TERM_CRITERIA_EPS:
+        eps = DBL_EPSILON
+    dev = _device_override if _device_override is not None else _device()
+    E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=_lib_override)
+    E.set_intr(0, np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], dist]))
+    # cvFindExtrinsicCameraParams2 per view: homography init + iterative refine
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    comm = _comm or _solver.Comm()
+    log = [] if _info is not None else None
+    err, iters = _solver.lm_pinhole(E, mask, maxc, eps, comm=comm, log=log)
+    n_total = comm.total(E.n_obs, dev)
+    rms = float(np.sqrt(err / n_total))
+    intr = E.get_intr(0)
+    poses = E.get_poses(0)
+    Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])
+    Dout = intr[4:4 + D.size].reshape(np.asarray(distCoeffs).shape)
+    if _info is not None:
+        _info.update(iters=iters, log=log, engine=E)
+    rv, tv = _poses_to_tuples(poses)
+    return rms, _write_back(cameraMatrix, Kout), _write_back(distCoeffs, Dout), rv, tv
+
+
+def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, tvecs=None, flags=0,
+                      criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON),
+                      *, _lib_override=None, _device_override=None, _comm=None, _info=None):
+    """``cv2.fisheye.calibrate`` on the MI355X (Kannala-Brandt, k1..k4).
+
+    Supported flag set: ``CALIB_USE_INTRINSIC_GUESS | CALIB_FIX_SKEW`` (both
+    required, as the reference always passes them) with optional
+    ``CALIB_RECOMPUTE_EXTRINSIC``, ``CALIB_FIX_K1..K4``,
+    ``CALIB_FIX_PRINCIPAL_POINT``, ``CALIB_FIX_FOCAL_LENGTH``.
+    """
+    flags = int(flags)
+    if flags & FISHEYE_CALIB_CHECK_COND:
+        raise error("CALIB_CHECK_COND is not supported")
+    if not flags & FISHEYE_CALIB_USE_INTRINSIC_GUESS:
+        raise error("CALIB_USE_INTRINSIC_GUESS is required (K / D must hold the guess)")
+    if not flags & FISHEYE_CALIB_FIX_SKEW:
+        raise error("skew estimation is not supported: pass fisheye.CALIB_FIX_SKEW")
+    if K is None or D is None:
+        raise error("(!K.empty() && !D.empty()) || !(flags & CALIB_USE_INTRINSIC_GUESS)")
+    Kin = np.asarray(K, dtype=np.float64)
+    Din = np.asarray(D, dtype=np.float64)
+    if Kin.shape != (3, 3):
+        raise error("K.size() == Size(3,3)")
+    if Din.size != 4:
+        raise error("D.total() == 4")
+    if Kin[0, 1] != 0.0:
+        raise error("a non-zero fixed skew is not supported")
+    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
+    mask = np.ones(8, dtype=bool)
+    if flags & FISHEYE_CALIB_FIX_FOCAL_LENGTH:
+        mask[0] = mask[1] = False
+    if flags & FISHEYE_CALIB_FIX_PRINCIPAL_POINT:
+        mask[2] = mask[3] = False
+    k = Din.ravel().copy()
+    for j, f in enumerate((FISHEYE_CALIB_FIX_K1, FISHEYE_CALIB_FIX_K2, FISHEYE_CALIB_FIX_K3,
+                           FISHEYE_CALIB_FIX_K4)):
+        if flags & f:
+            mask[4 + j] = False
+            k[j] = 0.0
+    dev = _device_override if _device_override is not None else _device()
+    E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=_lib_override)
+    E.set_intr(0, np.concatenate([[Kin[0, 0], Kin[1, 1], Kin[0, 2], Kin[1, 2]], k]))
+    # CalibrateExtrinsics: InitExtrinsics + ComputeExtrinsicRefine per view
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    comm = _comm or _solver.Comm()
+    log = [] if _info is not None else None
+    cost, iters = _solver.gn_fisheye(E, mask, tuple(criteria),
+                                     recompute_extrinsic=bool(flags & FISHEYE_CALIB_RECOMPUTE_EXTRINSIC),
+                                     comm=comm, log=log)
+    n_total = comm.total(E.n_obs, dev)
+    rms = float(np.sqrt(cost / n_total))
+    intr = E.get_intr(0)
+    poses = E.get_poses(0)
+    Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])
+    Dout = intr[4:8].reshape(np.asarray(D).shape)
+    if _info is not None:
+        _info.update(iters=iters, log=log, engine=E)
+    rv, tv = _poses_to_tuples(poses)
+    return rms, _write_back(K, Kout), _write_back(D, Dout), rv, tv

@@ -1,0 +1,448 @@
+// HIP kernels + C ABI of the calibration hot path for gfx950 (MI355X).
+//
+// Mapping: one lane == one view, one wavefront == one tile of 64 views, points
+// packed so that corner k of the 64 views of a tile is one coalesced 256-byte
+// row per component (see include/camcal.h).  All accumulators of a view live
+// in that lane's registers; the only cross-lane traffic is the 64-lane
+// butterfly at the end of the reducing kernels, followed by a fixed-order
+// second stage (deterministic sums).  FP64 VALU bound; no MFMA, no LDS tiling.
+//
+// Replaces the arithmetic the reference delegates to cv2.calibrateCamera /
+// cv2.fisheye.calibrate (server/aruco/camera_calib.py:74-77,153-156).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/camcal.h"
+#include "camcal_lane.h"
+
+using namespace camcal;
+
+namespace {
+
+constexpr int TPB = 256;                 // 4 wavefronts per workgroup
+constexpr int WPB = TPB / LANES;
+constexpr int MAX_WAVES = 4096;          // persistent waves of a reducing kernel (16 per CU)
+constexpr int MAX_NV = 64;               // widest reduced record (pinhole: 45 + 9 + 1 = 55)
+
+#define HIP_TRY(x)                                  \
+  do {                                              \
+    hipError_t e_ = (x);                            \
+    if (e_ != hipSuccess) return (int)e_;           \
+  } while (0)
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+template <int NV>
+__device__ __forceinline__ void wave_reduce_store(const double* v, double* scratch, int wave_id) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) scratch[(size_t)i * MAX_WAVES + wave_id] = s;
+  }
+}
+
+// second stage: out[i] = sum_w scratch[i][w], fixed order
+__global__ __launch_bounds__(TPB) void k_finalize(const double* __restrict__ scratch, int n_waves,
+                                                  double* __restrict__ out) {
+  __shared__ double sh[TPB];
+  const int i = blockIdx.x;
+  double s = 0.0;
+  for (int w = threadIdx.x; w < n_waves; w += TPB) s += scratch[(size_t)i * MAX_WAVES + w];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = TPB / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[i] = sh[0];
+}
+
+__device__ __forceinline__ LaneTile lane_tile(const camcal_tiles& t, int tile, int lane) {
+  LaneTile tv;
+  tv.base = t.pts + t.tile_off[tile] + lane;
+  tv.n = t.lane_n[(int64_t)tile * LANES + lane];
+  tv.nmax = t.tile_nmax[tile];
+  return tv;
+}
+
+__device__ __forceinline__ void load_pose(const double* __restrict__ pose, int64_t S, int64_t slot,
+                                          double p[6]) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) p[c] = pose[c * S + slot];
+}
+
+template <int NI>
+__device__ __forceinline__ void load_intr(const double* __restrict__ intr, double I[NI]) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i) I[i] = intr[i];
+}
+
+// ---------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_view_blocks(camcal_tiles t, const double* __restrict__ intr,
+                                                     const double* __restrict__ pose,
+                                                     double* __restrict__ Vb, double* __restrict__ Wb,
+                                                     double* __restrict__ gb) {
+  constexpr int NI = MT<MODEL>::NI;
+  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (tile >= t.n_tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
+  double I[NI], p[6];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, slot, p);
+  const LaneTile tv = lane_tile(t, tile, lane);
+  ViewAcc<MODEL> acc;
+  lane_view_blocks<MODEL>(tv, I, p, acc);
+#pragma unroll
+  for (int e = 0; e < 21; ++e) Vb[e * S + slot] = acc.V[e];
+#pragma unroll
+  for (int e = 0; e < NI * 6; ++e) Wb[e * S + slot] = acc.W[e];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) gb[e * S + slot] = acc.g[e];
+}
+
+template <int MODEL, bool NORMAL>
+__global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const double* __restrict__ intr,
+                                                     const double* __restrict__ pose,
+                                                     double* __restrict__ view_cost,
+                                                     double* __restrict__ scratch) {
+  constexpr int NI = MT<MODEL>::NI;
+  constexpr int NV = IntrAcc<MODEL>::NV;
+  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * WPB;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double I[NI];
+  load_intr<NI>(intr, I);
+  IntrAcc<MODEL> acc;
+  acc.zero();
+  for (int tile = wave; tile < t.n_tiles; tile += n_waves) {
+    const int64_t slot = (int64_t)tile * LANES + lane;
+    double p[6];
+    load_pose(pose, S, slot, p);
+    const LaneTile tv = lane_tile(t, tile, lane);
+    const double vc = lane_intr_normal<MODEL, NORMAL>(tv, I, p, acc);
+    if (view_cost) view_cost[slot] = vc;
+  }
+  if (NORMAL) {
+    wave_reduce_store<NV>(acc.v, scratch, wave);
+  } else {
+    const double s = wave_sum(acc.v[NV - 1]);
+    if (lane == 0) scratch[(size_t)(NV - 1) * MAX_WAVES + wave] = s;
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
+                                                     double* __restrict__ pose, int max_iter, double tol,
+                                                     int32_t* __restrict__ iters) {
+  constexpr int NI = MT<MODEL>::NI;
+  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (tile >= t.n_tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
+  const LaneTile tv = lane_tile(t, tile, lane);
+  if (tv.n < 4) { if (iters) iters[slot] = 0; return; }
+  double I[NI], p[6];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, slot, p);
+  const int it = lane_pose_refine<MODEL>(tv, I, p, max_iter, tol);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+  if (iters) iters[slot] = it;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_pose_init(camcal_tiles t, const double* __restrict__ intr,
+                                                   double* __restrict__ pose, int32_t* __restrict__ status) {
+  constexpr int NI = MT<MODEL>::NI;
+  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (tile >= t.n_tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
+  const LaneTile tv = lane_tile(t, tile, lane);
+  double I[NI];
+  load_intr<NI>(intr, I);
+  double p[6] = {0, 0, 0, 0, 0, 1};
+  const int st = lane_pose_init<MODEL>(tv, I, p);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+  if (status) status[slot] = tv.n == 0 ? 0 : st;
+}
+
+template <int NI>
+__global__ __launch_bounds__(TPB) void k_schur(camcal_tiles t, const double* __restrict__ Vb,
+                                               const double* __restrict__ Wb, const double* __restrict__ gb,
+                                               double lam, double* __restrict__ scratch) {
+  constexpr int NV = trisz(NI) + NI;
+  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * WPB;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+  for (int tile = wave; tile < t.n_tiles; tile += n_waves) {
+    const int64_t slot = (int64_t)tile * LANES + lane;
+    if (t.lane_n[slot] > 0) lane_schur<NI>(Vb, Wb, gb, S, slot, lam, acc);
+  }
+  wave_reduce_store<NV>(acc, scratch, wave);
+}
+
+template <int NI>
+__global__ __launch_bounds__(TPB) void k_backsub(camcal_tiles t, const double* __restrict__ Vb,
+                                                 const double* __restrict__ Wb, const double* __restrict__ gb,
+                                                 double lam, const double* __restrict__ dK,
+                                                 const double* __restrict__ pose_in,
+                                                 double* __restrict__ pose_out, double* __restrict__ scratch) {
+  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * WPB;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double dk[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) dk[i] = dK[i];
+  double acc[2] = {0.0, 0.0};
+  for (int tile = wave; tile < t.n_tiles; tile += n_waves) {
+    const int64_t slot = (int64_t)tile * LANES + lane;
+    double prev[6], out[6];
+    load_pose(pose_in, S, slot, prev);
+    if (t.lane_n[slot] > 0) {
+      double dd, pp;
+      lane_backsub<NI>(Vb, Wb, gb, S, slot, lam, dk, prev, out, dd, pp);
+      acc[0] += dd;
+      acc[1] += pp;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) out[c] = prev[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pose_out[c * S + slot] = out[c];
+  }
+  wave_reduce_store<2>(acc, scratch, wave);
+}
+
+// Reduced solve on one lane (see camcal_lane.h: reduced_solve).
+__global__ void k_solve_reduced(int NI, const double* __restrict__ glob, const double* __restrict__ schur,
+                                unsigned mask, double lam, double scale,
+                                const double* __restrict__ intr_in, double* __restrict__ intr_out,
+                                double* __restrict__ dK, double* __restrict__ stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  reduced_solve(NI, glob, schur, mask, lam, scale, intr_in, intr_out, dK, stats);
+}
+
+__global__ __launch_bounds__(TPB) void k_pack_tiles(const float* __restrict__ obj, const float* __restrict__ img,
+                                                    const int64_t* __restrict__ view_ptr,
+                                                    const int32_t* __restrict__ slot_view, camcal_tiles t,
+                                                    float* __restrict__ out) {
+  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (tile >= t.n_tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t slot = (int64_t)tile * LANES + lane;
+  const int v = slot_view[slot];
+  const int n = t.lane_n[slot];
+  const int nmax = t.tile_nmax[tile];
+  const int64_t p0 = v >= 0 ? view_ptr[v] : 0;
+  float* base = out + t.tile_off[tile] + lane;
+  for (int k = 0; k < nmax; ++k) {
+    float X = 0, Y = 0, Z = 0, u = 0, w = 0;
+    if (k < n) {
+      const float* o = obj + (p0 + k) * 3;
+      const float* m = img + (p0 + k) * 2;
+      X = o[0]; Y = o[1]; Z = o[2]; u = m[0]; w = m[1];
+    }
+    float* p = base + (int64_t)k * (PT_COMP * LANES);
+    p[0 * LANES] = X; p[1 * LANES] = Y; p[2 * LANES] = Z; p[3 * LANES] = u; p[4 * LANES] = w;
+  }
+}
+
+inline int tiles_ok(const camcal_tiles* t) {
+  if (!t || t->n_tiles <= 0 || t->n_slots != (int64_t)t->n_tiles * LANES) return 0;
+  if (!t->tile_off || !t->tile_nmax || !t->lane_n) return 0;
+  return 1;
+}
+inline int grid_tiles(const camcal_tiles* t) { return (t->n_tiles + WPB - 1) / WPB; }
+inline int grid_persistent(const camcal_tiles* t) {
+  const int g = grid_tiles(t);
+  return g < MAX_WAVES / WPB ? g : MAX_WAVES / WPB;
+}
+
+}  // namespace
+
+extern "C" {
+
+int camcal_version(void) { return 100; }
+int camcal_n_intr(int model) { return model == CAMCAL_PINHOLE ? 9 : model == CAMCAL_FISHEYE ? 8 : CAMCAL_E_BADMODEL; }
+int camcal_glob_len(int model) {
+  const int ni = camcal_n_intr(model);
+  return ni < 0 ? ni : ni * (ni + 1) / 2 + ni + 1;
+}
+int camcal_schur_len(int model) {
+  const int ni = camcal_n_intr(model);
+  return ni < 0 ? ni : ni * (ni + 1) / 2 + ni;
+}
+int64_t camcal_scratch_len(int model) {
+  (void)model;
+  return (int64_t)MAX_NV * MAX_WAVES;
+}
+
+int camcal_pack_tiles(const float* obj_xyz, const float* img_uv, const int64_t* view_ptr,
+                      const int32_t* slot_view, const camcal_tiles* tiles, float* pts_out, void* stream) {
+  if (!tiles_ok(tiles) || !obj_xyz || !img_uv || !view_ptr || !slot_view || !pts_out) return CAMCAL_E_BADARG;
+  hipLaunchKernelGGL(k_pack_tiles, dim3(grid_tiles(tiles)), dim3(TPB), 0, (hipStream_t)stream, obj_xyz, img_uv,
+                     view_ptr, slot_view, *tiles, pts_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_pose_init(int model, const camcal_tiles* tiles, const double* intr, double* pose, int32_t* status,
+                     void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose) return CAMCAL_E_BADARG;
+  const dim3 g(grid_tiles(tiles)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_pose_init<PINHOLE>, g, b, 0, s, *tiles, intr, pose, status);
+  else if (model == CAMCAL_FISHEYE) hipLaunchKernelGGL(k_pose_init<FISHEYE>, g, b, 0, s, *tiles, intr, pose, status);
+  else return CAMCAL_E_BADMODEL;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr, double* pose, int max_iter,
+                       double tol, int32_t* iters, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || max_iter < 0) return CAMCAL_E_BADARG;
+  const dim3 g(grid_tiles(tiles)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE)
+    hipLaunchKernelGGL(k_pose_refine<PINHOLE>, g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+  else if (model == CAMCAL_FISHEYE)
+    hipLaunchKernelGGL(k_pose_refine<FISHEYE>, g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+  else return CAMCAL_E_BADMODEL;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
+                       int with_normal, double* glob, double* view_cost, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !scratch) return CAMCAL_E_BADARG;
+  const int len = camcal_glob_len(model);
+  if (len < 0) return len;
+  const int gp = grid_persistent(tiles);
+  const dim3 g(gp), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) {
+    if (with_normal) hipLaunchKernelGGL((k_intr_normal<PINHOLE, true>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
+    else hipLaunchKernelGGL((k_intr_normal<PINHOLE, false>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
+  } else {
+    if (with_normal) hipLaunchKernelGGL((k_intr_normal<FISHEYE, true>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
+    else hipLaunchKernelGGL((k_intr_normal<FISHEYE, false>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
+  }
+  HIP_TRY(hipGetLastError());
+  if (with_normal) {
+    hipLaunchKernelGGL(k_finalize, dim3(len), dim3(TPB), 0, s, scratch, gp * WPB, glob);
+  } else {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)(len - 1) * MAX_WAVES, gp * WPB,
+                       glob + (len - 1));
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_view_blocks(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double* V,
+                       double* W, double* g, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !V || !W || !g) return CAMCAL_E_BADARG;
+  const dim3 gr(grid_tiles(tiles)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_view_blocks<PINHOLE>, gr, b, 0, s, *tiles, intr, pose, V, W, g);
+  else if (model == CAMCAL_FISHEYE) hipLaunchKernelGGL(k_view_blocks<FISHEYE>, gr, b, 0, s, *tiles, intr, pose, V, W, g);
+  else return CAMCAL_E_BADMODEL;
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_schur(int model, const camcal_tiles* tiles, const double* V, const double* W, const double* g,
+                 double lam, double* schur, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !V || !W || !g || !schur || !scratch) return CAMCAL_E_BADARG;
+  const int len = camcal_schur_len(model);
+  if (len < 0) return len;
+  const int gp = grid_persistent(tiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_schur<9>, dim3(gp), dim3(TPB), 0, s, *tiles, V, W, g, lam, scratch);
+  else hipLaunchKernelGGL(k_schur<8>, dim3(gp), dim3(TPB), 0, s, *tiles, V, W, g, lam, scratch);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize, dim3(len), dim3(TPB), 0, s, scratch, gp * WPB, schur);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_solve_reduced(int model, const double* glob, const double* schur, const uint8_t* mask_host, double lam,
+                         double scale, const double* intr_in, double* intr_out, double* dK, double* stats,
+                         void* stream) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  if (!glob || !schur || !mask_host || !intr_in || !intr_out || !dK || !stats) return CAMCAL_E_BADARG;
+  unsigned mask = 0;
+  for (int a = 0; a < ni; ++a)
+    if (mask_host[a]) mask |= 1u << a;
+  hipLaunchKernelGGL(k_solve_reduced, dim3(1), dim3(64), 0, (hipStream_t)stream, ni, glob, schur, mask, lam, scale,
+                     intr_in, intr_out, dK, stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_backsub(int model, const camcal_tiles* tiles, const double* V, const double* W, const double* g,
+                   double lam, const double* dK, const double* pose_in, double* pose_out, double* norms,
+                   double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !V || !W || !g || !dK || !pose_in || !pose_out || !norms || !scratch) return CAMCAL_E_BADARG;
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  const int gp = grid_persistent(tiles);
+  hipStream_t s = (hipStream_t)stream;
+  if (ni == 9) hipLaunchKernelGGL(k_backsub<9>, dim3(gp), dim3(TPB), 0, s, *tiles, V, W, g, lam, dK, pose_in, pose_out, scratch);
+  else hipLaunchKernelGGL(k_backsub<8>, dim3(gp), dim3(TPB), 0, s, *tiles, V, W, g, lam, dK, pose_in, pose_out, scratch);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize, dim3(2), dim3(TPB), 0, s, scratch, gp * WPB, norms);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                     double* V, double* W, double* g, double* glob, double* schur, double* scratch, void* stream) {
+  int rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
+  if (rc) return rc;
+  rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
+  if (rc) return rc;
+  return camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
+}
+
+int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles, const double* intr,
+                      const double* pose, double lam, double* V, double* W, double* g, double* glob, double* schur,
+                      double* scratch, void* stream, float* ms_out_host) {
+  if (reps <= 0 || !ms_out_host || stage < 0 || stage > 2) return CAMCAL_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  int rc = 0;
+  HIP_TRY(hipEventRecord(e0, s));
+  for (int r = 0; r < reps && rc == 0; ++r) {
+    if (stage == 0) rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
+    else if (stage == 1) rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
+    else rc = camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms_out_host = ms / reps;
+  return rc;
+}
+
+}  // extern "C"

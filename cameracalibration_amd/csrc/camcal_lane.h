@@ -1,0 +1,496 @@
+// Per-lane bodies of the calibration kernels: one lane == one view.
+// Shared by camcal_kernels.hip (device) and the tests' CPU lane emulator.
+// See camcal_math.h for conventions and the reference citations.
+#pragma once
+#include "camcal_math.h"
+
+namespace camcal {
+
+// One lane's window onto a packed tile.
+struct LaneTile {
+  const float* base;   // pts + tile_off + lane
+  int n;               // corners of this lane's view (0 for padding lanes)
+  int nmax;            // max corners over the tile's 64 lanes (loop bound)
+};
+
+struct Obs { float X, Y, Z, u, v; };
+
+CC_HD Obs load_obs(const float* base, int k) {
+  const float* p = base + (long long)k * (PT_COMP * LANES);
+  Obs o;
+  o.X = p[0 * LANES]; o.Y = p[1 * LANES]; o.Z = p[2 * LANES]; o.u = p[3 * LANES]; o.v = p[4 * LANES];
+  return o;
+}
+
+// ---------------------------------------------------------------------------
+// K1: per-view blocks V, W, g of the normal equations (Rodrigues frame).
+template <int MODEL>
+CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double pose[6],
+                            ViewAcc<MODEL>& acc) {
+  double R[9];
+  rodrigues(pose, R);
+  const double t[3] = {pose[3], pose[4], pose[5]};
+  acc.zero();
+  Obs cur = load_obs(tv.base, 0);
+  for (int k = 0; k < tv.nmax; ++k) {
+    const Obs nxt = load_obs(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);   // software prefetch
+    if (k < tv.n) {
+      double Yr[3], Yc[3];
+      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      PointEval<MODEL> p;
+      eval_point<true>(Yc, intr, p);
+      accumulate_view(acc, p, Yr, p.pu - (double)cur.u, p.pv - (double)cur.v);
+    }
+    cur = nxt;
+  }
+  double Jl[9];
+  left_jacobian(pose, Jl);
+  to_rodrigues_frame<MT<MODEL>::NI>(Jl, acc.V, acc.W, acc.g);
+}
+
+// ---------------------------------------------------------------------------
+// K2: intrinsic normal block U, b and the cost (global sums); also returns the
+// lane's own view cost (sum of squared residuals).  NORMAL=false: cost only.
+template <int MODEL, bool NORMAL>
+CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const double pose[6],
+                              IntrAcc<MODEL>& acc) {
+  double R[9];
+  rodrigues(pose, R);
+  const double t[3] = {pose[3], pose[4], pose[5]};
+  double vc = 0.0;
+  Obs cur = load_obs(tv.base, 0);
+  for (int k = 0; k < tv.nmax; ++k) {
+    const Obs nxt = load_obs(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
+    if (k < tv.n) {
+      double Yr[3], Yc[3];
+      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      PointEval<MODEL> p;
+      eval_point<NORMAL>(Yc, intr, p);
+      const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
+      if (NORMAL) accumulate_intr(acc, p, eu, ev);
+      vc += eu * eu + ev * ev;
+    }
+    cur = nxt;
+  }
+  if (!NORMAL) acc.v[IntrAcc<MODEL>::NV - 1] += vc;
+  return vc;
+}
+
+// ---------------------------------------------------------------------------
+// K4: per-view pose refinement with fixed intrinsics (Gauss-Newton), the
+// restatement of cv::internal::ComputeExtrinsicRefine: x += -(J^T J)^-1 J^T e,
+// stop when ||d|| / ||x + d|| <= tol or after max_iter steps.  Returns the
+// number of steps taken.  (cv2's cond(J) > 1e6 early-out is not evaluated.)
+template <int MODEL>
+CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6], int max_iter,
+                           double tol) {
+  int it = 0;
+  double change = 1.0;
+  while (change > tol && it < max_iter) {
+    double R[9];
+    rodrigues(pose, R);
+    const double t[3] = {pose[3], pose[4], pose[5]};
+    double V[21], g[6];
+    CC_UNROLL
+    for (int i = 0; i < 21; ++i) V[i] = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+    Obs cur = load_obs(tv.base, 0);
+    for (int k = 0; k < tv.n; ++k) {
+      const Obs nxt = load_obs(tv.base, (k + 1 < tv.n) ? k + 1 : k);
+      double Yr[3], Yc[3];
+      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      PointEval<MODEL> p;
+      eval_point<true>(Yc, intr, p);
+      const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
+      double ju[6], jv[6];
+      pose_row(Yr, p.gu, ju);
+      pose_row(Yr, p.gv, jv);
+      CC_UNROLL
+      for (int i = 0; i < 6; ++i) {
+        CC_UNROLL
+        for (int j = i; j < 6; ++j) V[tri(6, i, j)] += ju[i] * ju[j] + jv[i] * jv[j];
+        g[i] += eu * ju[i] + ev * jv[i];
+      }
+      cur = nxt;
+    }
+    double Jl[9];
+    left_jacobian(pose, Jl);
+    double Wdummy[6] = {0, 0, 0, 0, 0, 0};
+    to_rodrigues_frame<1>(Jl, V, Wdummy, g);
+    const bool ok = chol6(V);
+    chol6_fwd(V, g);
+    chol6_bwd(V, g);
+    if (!ok) break;
+    double d2 = 0.0, x2 = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < 6; ++i) {
+      const double xn = pose[i] - g[i];
+      d2 += g[i] * g[i];
+      x2 += xn * xn;
+      pose[i] = xn;
+    }
+    change = sqrt(d2) / sqrt(x2);
+    ++it;
+  }
+  return it;
+}
+
+// ---------------------------------------------------------------------------
+// K3: Schur complement contribution of one view.
+//   V' = V with diag * (1 + lam)   (lam = 0: undamped Gauss-Newton)
+//   C += W V'^-1 W^T (upper, NI(NI+1)/2),  d += W V'^-1 g
+// blocks are read component-major with stride S.  acc = [C | d].
+template <int NI>
+CC_HD void lane_schur(const double* Vb, const double* Wb, const double* gb, long long S,
+                      long long slot, double lam, double* acc) {
+  double V[21], z[6];
+  CC_UNROLL
+  for (int e = 0; e < 21; ++e) V[e] = Vb[e * S + slot];
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    V[tri(6, i, i)] *= 1.0 + lam;
+    z[i] = gb[i * S + slot];
+  }
+  chol6(V);
+  chol6_fwd(V, z);
+  double Y[NI * 6];
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) {
+    double y[6];
+    CC_UNROLL
+    for (int c = 0; c < 6; ++c) y[c] = Wb[(a * 6 + c) * S + slot];
+    chol6_fwd(V, y);
+    CC_UNROLL
+    for (int c = 0; c < 6; ++c) Y[a * 6 + c] = y[c];
+  }
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) {
+    CC_UNROLL
+    for (int b = a; b < NI; ++b) {
+      double s = 0.0;
+      CC_UNROLL
+      for (int c = 0; c < 6; ++c) s += Y[a * 6 + c] * Y[b * 6 + c];
+      acc[tri(NI, a, b)] += s;
+    }
+    double s = 0.0;
+    CC_UNROLL
+    for (int c = 0; c < 6; ++c) s += Y[a * 6 + c] * z[c];
+    acc[trisz(NI) + a] += s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5: back-substitution  d_i = V'^-1 (g - W^T dK);  pose_new = pose_prev - d_i.
+// Returns ||d_i||^2 through dd and ||pose_prev||^2 through pp.
+template <int NI>
+CC_HD void lane_backsub(const double* Vb, const double* Wb, const double* gb, long long S,
+                        long long slot, double lam, const double* dK, const double prev[6],
+                        double out[6], double& dd, double& pp) {
+  double V[21], rhs[6];
+  CC_UNROLL
+  for (int e = 0; e < 21; ++e) V[e] = Vb[e * S + slot];
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    V[tri(6, i, i)] *= 1.0 + lam;
+    rhs[i] = gb[i * S + slot];
+  }
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) {
+    const double dk = dK[a];
+    CC_UNROLL
+    for (int c = 0; c < 6; ++c) rhs[c] -= Wb[(a * 6 + c) * S + slot] * dk;
+  }
+  chol6(V);
+  chol6_fwd(V, rhs);
+  chol6_bwd(V, rhs);
+  dd = 0.0; pp = 0.0;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    out[i] = prev[i] - rhs[i];
+    dd += rhs[i] * rhs[i];
+    pp += prev[i] * prev[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Pixel -> normalised, distortion removed (pose initialisation only).
+template <int MODEL> CC_HD void undistort_px(double u, double v, const double* intr, double& mx, double& my);
+
+// cvUndistortPointsInternal: 5 fixed-point sweeps
+template <> CC_HD void undistort_px<PINHOLE>(double u, double v, const double* intr, double& mx, double& my) {
+  const double k1 = intr[4], k2 = intr[5], p1 = intr[6], p2 = intr[7], k3 = intr[8];
+  const double x0 = (u - intr[2]) / intr[0], y0 = (v - intr[3]) / intr[1];
+  double x = x0, y = y0;
+  for (int it = 0; it < 5; ++it) {
+    const double r2 = x * x + y * y;
+    const double icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
+    if (icd < 0) { x = x0; y = y0; break; }
+    const double dX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+    const double dY = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+    x = (x0 - dX) * icd;
+    y = (y0 - dY) * icd;
+  }
+  mx = x; my = y;
+}
+
+// cv::fisheye::undistortPoints: Newton on theta (<= 10 steps, |fix| < 1e-8)
+template <> CC_HD void undistort_px<FISHEYE>(double u, double v, const double* intr, double& mx, double& my) {
+  const double k1 = intr[4], k2 = intr[5], k3 = intr[6], k4 = intr[7];
+  const double px = (u - intr[2]) / intr[0], py = (v - intr[3]) / intr[1];
+  double thd = sqrt(px * px + py * py);
+  const double hp = 1.5707963267948966;
+  thd = thd > hp ? hp : thd;
+  double scale = 1.0;
+  if (thd > 1e-8) {
+    double th = thd;
+    for (int j = 0; j < 10; ++j) {
+      const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+      const double fix = (th * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8) - thd) /
+                         (1 + 3 * k1 * t2 + 5 * k2 * t4 + 7 * k3 * t6 + 9 * k4 * t8);
+      th -= fix;
+      if (fabs(fix) < 1e-8) break;
+    }
+    scale = tan(th) / thd;
+  }
+  mx = px * scale; my = py * scale;
+}
+
+// packed SPD solve A x = b, A upper (N(N+1)/2), in place; returns false on a bad pivot
+template <int N>
+CC_HD bool chol_solve(double* A, double* b) {
+  bool ok = true;
+  CC_UNROLL
+  for (int i = 0; i < N; ++i) {
+    double d = A[tri(N, i, i)];
+    CC_UNROLL
+    for (int k = 0; k < i; ++k) d -= A[tri(N, k, i)] * A[tri(N, k, i)];
+    ok = ok && (d > 0.0);
+    const double u = sqrt(d > 0.0 ? d : 1.0);
+    A[tri(N, i, i)] = u;
+    CC_UNROLL
+    for (int j = i + 1; j < N; ++j) {
+      double s = A[tri(N, i, j)];
+      CC_UNROLL
+      for (int k = 0; k < i; ++k) s -= A[tri(N, k, i)] * A[tri(N, k, j)];
+      A[tri(N, i, j)] = s / u;
+    }
+  }
+  CC_UNROLL
+  for (int i = 0; i < N; ++i) {
+    double s = b[i];
+    CC_UNROLL
+    for (int k = 0; k < i; ++k) s -= A[tri(N, k, i)] * b[k];
+    b[i] = s / A[tri(N, i, i)];
+  }
+  CC_UNROLL
+  for (int i = N - 1; i >= 0; --i) {
+    double s = b[i];
+    CC_UNROLL
+    for (int k = i + 1; k < N; ++k) s -= A[tri(N, i, k)] * b[k];
+    b[i] = s / A[tri(N, i, i)];
+  }
+  return ok;
+}
+
+// rotation matrix (row-major) -> Rodrigues vector, via the unit quaternion
+CC_HD void rot_to_rvec(const double R[9], double r[3]) {
+  const double tr = R[0] + R[4] + R[8];
+  double qw, qx, qy, qz;
+  if (tr > 0.0) {
+    const double S = sqrt(tr + 1.0) * 2.0;
+    qw = 0.25 * S; qx = (R[7] - R[5]) / S; qy = (R[2] - R[6]) / S; qz = (R[3] - R[1]) / S;
+  } else if (R[0] > R[4] && R[0] > R[8]) {
+    const double S = sqrt(1.0 + R[0] - R[4] - R[8]) * 2.0;
+    qw = (R[7] - R[5]) / S; qx = 0.25 * S; qy = (R[1] + R[3]) / S; qz = (R[2] + R[6]) / S;
+  } else if (R[4] > R[8]) {
+    const double S = sqrt(1.0 + R[4] - R[0] - R[8]) * 2.0;
+    qw = (R[2] - R[6]) / S; qx = (R[1] + R[3]) / S; qy = 0.25 * S; qz = (R[5] + R[7]) / S;
+  } else {
+    const double S = sqrt(1.0 + R[8] - R[0] - R[4]) * 2.0;
+    qw = (R[3] - R[1]) / S; qx = (R[2] + R[6]) / S; qy = (R[5] + R[7]) / S; qz = 0.25 * S;
+  }
+  if (qw < 0.0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+  const double vn = sqrt(qx * qx + qy * qy + qz * qz);
+  const double sc = vn > 1e-12 ? 2.0 * atan2(vn, qw) / vn : 2.0;
+  r[0] = qx * sc; r[1] = qy * sc; r[2] = qz * sc;
+}
+
+// ---------------------------------------------------------------------------
+// K6: pose initialisation of one planar (Z = 0) view, the structure of
+// cv::internal::InitExtrinsics / cvFindExtrinsicCameraParams2 (planar branch):
+// undistort -> homography (normalised DLT, then Gauss-Newton on the transfer
+// error, <= 10 steps) -> (u1, u2 - (u1.u2)u1, u1 x u2) -> Rodrigues vector,
+// t = h3 / sc - R [mx my 0]^T.  Returns 0 on success.
+template <int MODEL>
+CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6]) {
+  const int n = tv.n;
+  if (n < 4) return 1;
+  // pass 1: centroid / spread of the board points
+  double sx = 0, sy = 0, sxx = 0, syy = 0;
+  for (int k = 0; k < n; ++k) {
+    const Obs o = load_obs(tv.base, k);
+    sx += o.X; sy += o.Y; sxx += (double)o.X * o.X; syy += (double)o.Y * o.Y;
+  }
+  const double inv_n = 1.0 / n;
+  const double mX = sx * inv_n, mY = sy * inv_n;
+  double dX = sqrt(fmax(sxx * inv_n - mX * mX, 0.0)), dY = sqrt(fmax(syy * inv_n - mY * mY, 0.0));
+  const double iX = dX > 1e-300 ? 1.0 / dX : 1.0, iY = dY > 1e-300 ? 1.0 / dY : 1.0;
+  // pass 2: inhomogeneous DLT (h33 = 1) in normalised board coordinates
+  double A[36], b[8];
+  CC_UNROLL
+  for (int i = 0; i < 36; ++i) A[i] = 0.0;
+  CC_UNROLL
+  for (int i = 0; i < 8; ++i) b[i] = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const Obs o = load_obs(tv.base, k);
+    double x, y;
+    undistort_px<MODEL>(o.u, o.v, intr, x, y);
+    const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
+    // rows: [X Y 1 0 0 0 -xX -xY | x], [0 0 0 X Y 1 -yX -yY | y]
+    const double r0[8] = {X, Y, 1.0, 0.0, 0.0, 0.0, -x * X, -x * Y};
+    const double r1[8] = {0.0, 0.0, 0.0, X, Y, 1.0, -y * X, -y * Y};
+    CC_UNROLL
+    for (int i = 0; i < 8; ++i) {
+      CC_UNROLL
+      for (int j = i; j < 8; ++j) A[tri(8, i, j)] += r0[i] * r0[j] + r1[i] * r1[j];
+      b[i] += r0[i] * x + r1[i] * y;
+    }
+  }
+  if (!chol_solve<8>(A, b)) return 2;
+  double h[8];
+  CC_UNROLL
+  for (int i = 0; i < 8; ++i) h[i] = b[i];
+  // Gauss-Newton on the transfer error  sum |H X - m|^2
+  for (int it = 0; it < 10; ++it) {
+    CC_UNROLL
+    for (int i = 0; i < 36; ++i) A[i] = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < 8; ++i) b[i] = 0.0;
+    for (int k = 0; k < n; ++k) {
+      const Obs o = load_obs(tv.base, k);
+      double x, y;
+      undistort_px<MODEL>(o.u, o.v, intr, x, y);
+      const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
+      const double iw = 1.0 / (h[6] * X + h[7] * Y + 1.0);
+      const double px = (h[0] * X + h[1] * Y + h[2]) * iw, py = (h[3] * X + h[4] * Y + h[5]) * iw;
+      const double ex = px - x, ey = py - y;
+      const double Xw = X * iw, Yw = Y * iw;
+      const double r0[8] = {Xw, Yw, iw, 0.0, 0.0, 0.0, -px * Xw, -px * Yw};
+      const double r1[8] = {0.0, 0.0, 0.0, Xw, Yw, iw, -py * Xw, -py * Yw};
+      CC_UNROLL
+      for (int i = 0; i < 8; ++i) {
+        CC_UNROLL
+        for (int j = i; j < 8; ++j) A[tri(8, i, j)] += r0[i] * r0[j] + r1[i] * r1[j];
+        b[i] += r0[i] * ex + r1[i] * ey;
+      }
+    }
+    if (!chol_solve<8>(A, b)) break;
+    double dmax = 0.0, hmax = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < 8; ++i) {
+      h[i] -= b[i];
+      dmax = fmax(dmax, fabs(b[i]));
+      hmax = fmax(hmax, fabs(h[i]));
+    }
+    if (dmax <= 1e-13 * hmax) break;
+  }
+  // columns of the homography in centred board millimetres
+  double h1[3] = {h[0] * iX, h[3] * iX, h[6] * iX};
+  double h2[3] = {h[1] * iY, h[4] * iY, h[7] * iY};
+  const double h3[3] = {h[2], h[5], 1.0};
+  const double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
+  const double n2 = sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2]);
+  if (!(n1 > 0.0) || !(n2 > 0.0)) return 3;
+  const double isc = 2.0 / (n1 + n2);
+  double u1[3] = {h1[0] / n1, h1[1] / n1, h1[2] / n1};
+  const double dot = u1[0] * h2[0] + u1[1] * h2[1] + u1[2] * h2[2];
+  double u2[3] = {h2[0] - dot * u1[0], h2[1] - dot * u1[1], h2[2] - dot * u1[2]};
+  const double m2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+  if (!(m2 > 0.0)) return 3;
+  u2[0] /= m2; u2[1] /= m2; u2[2] /= m2;
+  const double u3[3] = {u1[1] * u2[2] - u1[2] * u2[1], u1[2] * u2[0] - u1[0] * u2[2], u1[0] * u2[1] - u1[1] * u2[0]};
+  const double R[9] = {u1[0], u2[0], u3[0], u1[1], u2[1], u3[1], u1[2], u2[2], u3[2]};
+  rot_to_rvec(R, pose);
+  pose[3] = h3[0] * isc - (R[0] * mX + R[1] * mY);
+  pose[4] = h3[1] * isc - (R[3] * mX + R[4] * mY);
+  pose[5] = h3[2] * isc - (R[6] * mX + R[7] * mY);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Reduced solve (U' - C) dK = b - d on the free intrinsics: symmetric Jacobi
+// scaling + Gaussian elimination with partial pivoting (single lane; NI <= 9).
+// glob = [U | b | cost], schur = [C | d]; intr_out = intr_in + scale * dK.
+// The eliminated form of CvLevMarq::step / fisheye::calibrate's solve(JJ2, ex3).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void reduced_solve(int NI, const double* glob, const double* schur, unsigned mask, double lam,
+                          double scale, const double* intr_in, double* intr_out, double* dK,
+                          double* stats) {
+  const int NU = NI * (NI + 1) / 2;
+  double A[9 * 10];
+  int idx[9];
+  int nf = 0;
+  for (int a = 0; a < NI; ++a)
+    if (mask & (1u << a)) idx[nf++] = a;
+  auto tr = [NI](int i, int j) { return i <= j ? i * NI - (i * (i - 1)) / 2 + (j - i) : j * NI - (j * (j - 1)) / 2 + (i - j); };
+  double sc[9];
+  for (int i = 0; i < nf; ++i) {
+    const int a = idx[i];
+    const double d = glob[tr(a, a)] * (1.0 + lam) - schur[tr(a, a)];
+    sc[i] = d > 0.0 ? 1.0 / sqrt(d) : 1.0;
+  }
+  for (int i = 0; i < nf; ++i) {
+    const int a = idx[i];
+    for (int j = 0; j < nf; ++j) {
+      const int b = idx[j];
+      double u = glob[tr(a, b)];
+      if (a == b) u *= 1.0 + lam;
+      A[i * 10 + j] = (u - schur[tr(a, b)]) * sc[i] * sc[j];
+    }
+    A[i * 10 + 9] = (glob[NU + a] - schur[NU + a]) * sc[i];
+  }
+  double okf = 1.0;
+  for (int c = 0; c < nf; ++c) {
+    int piv = c;
+    double best = fabs(A[c * 10 + c]);
+    for (int r = c + 1; r < nf; ++r)
+      if (fabs(A[r * 10 + c]) > best) { best = fabs(A[r * 10 + c]); piv = r; }
+    if (!(best > 0.0)) { okf = 0.0; continue; }
+    if (piv != c)
+      for (int k = 0; k < 10; ++k) { const double tmp = A[c * 10 + k]; A[c * 10 + k] = A[piv * 10 + k]; A[piv * 10 + k] = tmp; }
+    const double ip = 1.0 / A[c * 10 + c];
+    for (int r = c + 1; r < nf; ++r) {
+      const double f = A[r * 10 + c] * ip;
+      if (f != 0.0) {
+        for (int k = c; k < nf; ++k) A[r * 10 + k] -= f * A[c * 10 + k];
+        A[r * 10 + 9] -= f * A[c * 10 + 9];
+      }
+    }
+  }
+  double x[9];
+  for (int c = nf - 1; c >= 0; --c) {
+    double s = A[c * 10 + 9];
+    for (int k = c + 1; k < nf; ++k) s -= A[c * 10 + k] * x[k];
+    x[c] = A[c * 10 + c] != 0.0 ? s / A[c * 10 + c] : 0.0;
+  }
+  double d[9];
+  for (int a = 0; a < NI; ++a) d[a] = 0.0;
+  for (int i = 0; i < nf; ++i) d[idx[i]] = x[i] * sc[i];
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int a = 0; a < NI; ++a) {
+    const double in = intr_in[a];
+    const double st = scale * d[a];
+    const double out = in + st;
+    dK[a] = d[a];
+    intr_out[a] = out;
+    s0 += st * st;
+    s1 += in * in;
+    if (a < 4) { s2 += st * st; s3 += out * out; }
+  }
+  stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; stats[4] = okf;
+}
+
+}  // namespace camcal

@@ -1,0 +1,351 @@
+// Lane-level math of the calibration hot path (fp64), shared by the HIP kernels
+// (camcal_kernels.hip) and by the CPU lane emulator that only the tests build
+// (tests/hostemu/).  One "lane" owns one view: it walks that view's corner
+// observations and keeps every accumulator in registers, so no cross-lane
+// traffic is needed until the final block reduction.
+//
+// Replaces the arithmetic that the reference delegates to cv2.calibrateCamera
+// (server/aruco/camera_calib.py:153-156) and cv2.fisheye.calibrate
+// (server/aruco/camera_calib.py:74-77); model definitions follow OpenCV 4.10
+// cvProjectPoints2Internal / cv::fisheye::projectPoints as recalled in
+// SURVEY.md 8(c)-appendix.
+//
+// Conventions
+//   residual        e = projected - observed
+//   pinhole intr    [fx fy cx cy k1 k2 p1 p2 k3]     NI = 9
+//   fisheye intr    [fx fy cx cy k1 k2 k3 k4]        NI = 8  (skew fixed at 0)
+//   pose            [r0 r1 r2 t0 t1 t2]  (Rodrigues vector, translation)
+//   packed points   tile = 64 consecutive slots (views); float at
+//                   tile_off + (k*5 + c)*64 + lane,  c in {X,Y,Z,u,v}
+//   per-view blocks V (6x6 upper, 21), W (NI x 6 row-major), g (6), stored
+//                   component-major: block[e * n_slots + slot]
+//
+// The pose columns are accumulated in the local tangent frame
+// (dY/dw = -[R X]x, dY/dt = I) and mapped once per view to Rodrigues
+// coordinates with the SO(3) left Jacobian Jl(r):  d(RX)/dr = -[R X]x Jl(r),
+// which equals cv2's (dR/dr) X chain exactly (checked in tests against
+// cvRodrigues2's 3x9 derivative).
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define CC_HD __host__ __device__ __forceinline__
+#define CC_UNROLL _Pragma("unroll")
+#else
+#define CC_HD inline
+#define CC_UNROLL
+#endif
+
+namespace camcal {
+
+constexpr int PINHOLE = 0;
+constexpr int FISHEYE = 1;
+constexpr int LANES = 64;      // wavefront width == views per tile
+constexpr int PT_COMP = 5;     // X Y Z u v
+
+template <int MODEL> struct MT;
+template <> struct MT<PINHOLE> {
+  static constexpr int NI = 9;   // free-able intrinsics
+  static constexpr int NA = 7;   // non-zero intrinsic columns per image row
+  // columns touched by the u row / the v row; entry 1 is the unit cx / cy column
+  static constexpr int ucol(int a) { return a == 0 ? 0 : a == 1 ? 2 : a + 2; }
+  static constexpr int vcol(int a) { return a == 0 ? 1 : a == 1 ? 3 : a + 2; }
+};
+template <> struct MT<FISHEYE> {
+  static constexpr int NI = 8;
+  static constexpr int NA = 6;
+  static constexpr int ucol(int a) { return a == 0 ? 0 : a == 1 ? 2 : a + 2; }
+  static constexpr int vcol(int a) { return a == 0 ? 1 : a == 1 ? 3 : a + 2; }
+};
+
+// upper-triangle index of an n x n symmetric matrix, i <= j
+CC_HD constexpr int tri(int n, int i, int j) { return i * n - (i * (i - 1)) / 2 + (j - i); }
+CC_HD constexpr int trisz(int n) { return n * (n + 1) / 2; }
+
+// ---------------------------------------------------------------------------
+// Rodrigues vector -> rotation matrix (row-major), as cvRodrigues2.
+CC_HD void rodrigues(const double r[3], double R[9]) {
+  const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const double th = sqrt(th2);
+  if (th < 2.220446049250313e-16) {
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    return;
+  }
+  const double s = sin(th), c = cos(th), c1 = 1.0 - c, it = 1.0 / th;
+  const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+  R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+  R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+  R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+
+// SO(3) left Jacobian Jl(r) = I + B [r]x + C [r]x^2 (row-major).
+CC_HD void left_jacobian(const double r[3], double J[9]) {
+  const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  double B, C;
+  if (th2 < 0.25) {
+    // series: B = (1-cos t)/t^2, C = (t - sin t)/t^3
+    B = 0.5 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 + th2 * (-1.0 / 40320 + th2 * (1.0 / 3628800 +
+        th2 * (-1.0 / 479001600 + th2 * (1.0 / 87178291200.0))))));
+    C = 1.0 / 6 + th2 * (-1.0 / 120 + th2 * (1.0 / 5040 + th2 * (-1.0 / 362880 + th2 * (1.0 / 39916800 +
+        th2 * (-1.0 / 6227020800.0 + th2 * (1.0 / 1307674368000.0))))));
+  } else {
+    const double th = sqrt(th2);
+    const double sh = sin(0.5 * th);
+    B = 2.0 * sh * sh / th2;
+    C = (th - sin(th)) / (th2 * th);
+  }
+  const double x = r[0], y = r[1], z = r[2];
+  // [r]x^2 = r r^T - th2 I
+  J[0] = 1.0 + C * (x * x - th2); J[1] = -B * z + C * x * y;        J[2] = B * y + C * x * z;
+  J[3] = B * z + C * x * y;       J[4] = 1.0 + C * (y * y - th2);   J[5] = -B * x + C * y * z;
+  J[6] = -B * y + C * x * z;      J[7] = B * x + C * y * z;         J[8] = 1.0 + C * (z * z - th2);
+}
+
+// ---------------------------------------------------------------------------
+// Per-observation evaluation in the camera frame.
+template <int MODEL> struct PointEval {
+  double pu, pv;             // projected pixel
+  double gu[3], gv[3];       // d pu / dY, d pv / dY   (Y = camera-frame point)
+  double au[MT<MODEL>::NA];  // intrinsic columns of the u row (au[1] == 1: cx)
+  double av[MT<MODEL>::NA];  // intrinsic columns of the v row (av[1] == 1: cy)
+};
+
+// pinhole, 5 coefficients: intr = fx fy cx cy k1 k2 p1 p2 k3
+template <bool JAC>
+CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<PINHOLE>& o) {
+  const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const double k1 = intr[4], k2 = intr[5], p1 = intr[6], p2 = intr[7], k3 = intr[8];
+  const double z = Yc[2] != 0.0 ? 1.0 / Yc[2] : 1.0;
+  const double x = Yc[0] * z, y = Yc[1] * z;
+  const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+  const double cdist = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+  const double xd = x * cdist + p1 * a1 + p2 * a2;
+  const double yd = y * cdist + p1 * a3 + p2 * a1;
+  o.pu = xd * fx + cx;
+  o.pv = yd * fy + cy;
+  if (JAC) {
+    o.au[0] = xd; o.au[1] = 1.0;
+    o.av[0] = yd; o.av[1] = 1.0;
+    const double fxx = fx * x, fyy = fy * y;
+    o.au[2] = fxx * r2; o.av[2] = fyy * r2;
+    o.au[3] = fxx * r4; o.av[3] = fyy * r4;
+    o.au[4] = fx * a1;  o.av[4] = fy * a3;
+    o.au[5] = fx * a2;  o.av[5] = fy * a1;
+    o.au[6] = fxx * r6; o.av[6] = fyy * r6;
+    const double g = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+    const double dxdx = cdist + 2.0 * x * x * g + 2.0 * p1 * y + 6.0 * p2 * x;
+    const double dxdy = 2.0 * x * y * g + 2.0 * p1 * x + 2.0 * p2 * y;
+    const double dydy = cdist + 2.0 * y * y * g + 6.0 * p1 * y + 2.0 * p2 * x;
+    const double fxz = fx * z, fyz = fy * z;
+    o.gu[0] = fxz * dxdx; o.gu[1] = fxz * dxdy; o.gu[2] = -fxz * (x * dxdx + y * dxdy);
+    o.gv[0] = fyz * dxdy; o.gv[1] = fyz * dydy; o.gv[2] = -fyz * (x * dxdy + y * dydy);
+  }
+}
+
+// Kannala-Brandt fisheye: intr = fx fy cx cy k1 k2 k3 k4 (skew 0)
+template <bool JAC>
+CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>& o) {
+  const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const double k1 = intr[4], k2 = intr[5], k3 = intr[6], k4 = intr[7];
+  const double iz = 1.0 / Yc[2];
+  const double x = Yc[0] * iz, y = Yc[1] * iz;
+  const double r2 = x * x + y * y;
+  const double rr = sqrt(r2);
+  const bool big = rr > 1e-8;
+  const double inv_r = big ? 1.0 / rr : 1.0;
+  const double th = atan(rr);
+  const double th2 = th * th;
+  const double poly = 1.0 + th2 * (k1 + th2 * (k2 + th2 * (k3 + th2 * k4)));
+  const double cdist = big ? th * poly * inv_r : 1.0;
+  const double xd = x * cdist, yd = y * cdist;
+  o.pu = xd * fx + cx;
+  o.pv = yd * fy + cy;
+  if (JAC) {
+    o.au[0] = xd; o.au[1] = 1.0;
+    o.av[0] = yd; o.av[1] = 1.0;
+    double tp = th * th2 * inv_r;       // theta^3 / r
+    const double fxx = fx * x, fyy = fy * y;
+    o.au[2] = fxx * tp; o.av[2] = fyy * tp; tp *= th2;
+    o.au[3] = fxx * tp; o.av[3] = fyy * tp; tp *= th2;
+    o.au[4] = fxx * tp; o.av[4] = fyy * tp; tp *= th2;
+    o.au[5] = fxx * tp; o.av[5] = fyy * tp;
+    const double dpoly = 1.0 + th2 * (3.0 * k1 + th2 * (5.0 * k2 + th2 * (7.0 * k3 + th2 * 9.0 * k4)));
+    // s(r) = theta_d / r ;  q = (ds/dr)/r
+    const double q = big ? (dpoly / (1.0 + r2) - cdist) * inv_r * inv_r : 0.0;
+    const double a = cdist + x * x * q, b = x * y * q, c = cdist + y * y * q;
+    const double fxz = fx * iz, fyz = fy * iz;
+    o.gu[0] = fxz * a; o.gu[1] = fxz * b; o.gu[2] = -fxz * (x * a + y * b);
+    o.gv[0] = fyz * b; o.gv[1] = fyz * c; o.gv[2] = -fyz * (x * b + y * c);
+  }
+}
+
+// camera-frame point and its rotated part
+CC_HD void transform_point(const double R[9], const double t[3], float X, float Y, float Z,
+                           double Yr[3], double Yc[3]) {
+  const double Xd = X, Yd = Y, Zd = Z;
+  Yr[0] = R[0] * Xd + R[1] * Yd + R[2] * Zd;
+  Yr[1] = R[3] * Xd + R[4] * Yd + R[5] * Zd;
+  Yr[2] = R[6] * Xd + R[7] * Yd + R[8] * Zd;
+  Yc[0] = Yr[0] + t[0]; Yc[1] = Yr[1] + t[1]; Yc[2] = Yr[2] + t[2];
+}
+
+// local-frame pose row j = [Yr x g, g]
+CC_HD void pose_row(const double Yr[3], const double g[3], double j[6]) {
+  j[0] = Yr[1] * g[2] - Yr[2] * g[1];
+  j[1] = Yr[2] * g[0] - Yr[0] * g[2];
+  j[2] = Yr[0] * g[1] - Yr[1] * g[0];
+  j[3] = g[0]; j[4] = g[1]; j[5] = g[2];
+}
+
+// ---------------------------------------------------------------------------
+// Accumulator sets
+template <int MODEL> struct ViewAcc {   // per-view blocks in the local pose frame
+  static constexpr int NI = MT<MODEL>::NI;
+  double V[21];
+  double W[NI * 6];
+  double g[6];
+  CC_HD void zero() {
+    CC_UNROLL
+    for (int i = 0; i < 21; ++i) V[i] = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < NI * 6; ++i) W[i] = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  }
+};
+
+template <int MODEL> struct IntrAcc {   // global intrinsic normal block
+  static constexpr int NI = MT<MODEL>::NI;
+  static constexpr int NU = trisz(NI);
+  static constexpr int NV = NU + NI + 1;   // U | b | cost
+  double v[NV];
+  CC_HD void zero() { for (int i = 0; i < NV; ++i) v[i] = 0.0; }
+};
+
+template <int MODEL>
+CC_HD void accumulate_view(ViewAcc<MODEL>& A, const PointEval<MODEL>& p, const double Yr[3],
+                           double eu, double ev) {
+  using T = MT<MODEL>;
+  double ju[6], jv[6];
+  pose_row(Yr, p.gu, ju);
+  pose_row(Yr, p.gv, jv);
+CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+CC_UNROLL
+    for (int j = i; j < 6; ++j) A.V[tri(6, i, j)] += ju[i] * ju[j] + jv[i] * jv[j];
+    A.g[i] += eu * ju[i] + ev * jv[i];
+  }
+CC_UNROLL
+  for (int a = 0; a < T::NA; ++a) {
+CC_UNROLL
+    for (int c = 0; c < 6; ++c) {
+      A.W[T::ucol(a) * 6 + c] += p.au[a] * ju[c];
+      A.W[T::vcol(a) * 6 + c] += p.av[a] * jv[c];
+    }
+  }
+}
+
+template <int MODEL>
+CC_HD void accumulate_intr(IntrAcc<MODEL>& A, const PointEval<MODEL>& p, double eu, double ev) {
+  using T = MT<MODEL>;
+  constexpr int NI = T::NI;
+  constexpr int NU = trisz(NI);
+CC_UNROLL
+  for (int a = 0; a < T::NA; ++a) {
+CC_UNROLL
+    for (int b = a; b < T::NA; ++b) {
+      A.v[tri(NI, T::ucol(a), T::ucol(b))] += p.au[a] * p.au[b];
+      A.v[tri(NI, T::vcol(a), T::vcol(b))] += p.av[a] * p.av[b];
+    }
+    A.v[NU + T::ucol(a)] += p.au[a] * eu;
+    A.v[NU + T::vcol(a)] += p.av[a] * ev;
+  }
+  A.v[NU + NI] += eu * eu + ev * ev;
+}
+
+// Map the local-frame blocks of one view to Rodrigues coordinates (in place):
+// V <- T^T V T, W <- W T, g <- T^T g with T = diag(Jl, I3).
+template <int NI>
+CC_HD void to_rodrigues_frame(const double Jl[9], double V[21], double* W, double g[6]) {
+  // A = V[0:3,0:3] (sym), B = V[0:3,3:6]
+  double A[9], B[9];
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      A[i * 3 + j] = V[i <= j ? tri(6, i, j) : tri(6, j, i)];
+      B[i * 3 + j] = V[tri(6, i, 3 + j)];
+    }
+  double AJ[9];
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j)
+      AJ[i * 3 + j] = A[i * 3 + 0] * Jl[0 * 3 + j] + A[i * 3 + 1] * Jl[1 * 3 + j] + A[i * 3 + 2] * Jl[2 * 3 + j];
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = i; j < 3; ++j)
+      V[tri(6, i, j)] = Jl[0 * 3 + i] * AJ[0 * 3 + j] + Jl[1 * 3 + i] * AJ[1 * 3 + j] + Jl[2 * 3 + i] * AJ[2 * 3 + j];
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j)
+      V[tri(6, i, 3 + j)] = Jl[0 * 3 + i] * B[0 * 3 + j] + Jl[1 * 3 + i] * B[1 * 3 + j] + Jl[2 * 3 + i] * B[2 * 3 + j];
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) {
+    const double w0 = W[a * 6 + 0], w1 = W[a * 6 + 1], w2 = W[a * 6 + 2];
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j) W[a * 6 + j] = w0 * Jl[0 * 3 + j] + w1 * Jl[1 * 3 + j] + w2 * Jl[2 * 3 + j];
+  }
+  const double g0 = g[0], g1 = g[1], g2 = g[2];
+  CC_UNROLL
+  for (int j = 0; j < 3; ++j) g[j] = Jl[0 * 3 + j] * g0 + Jl[1 * 3 + j] * g1 + Jl[2 * 3 + j] * g2;
+}
+
+// In-place Cholesky of a 6x6 SPD matrix stored as upper triangle (21): on
+// return V holds U with V = U^T U.  Returns false if a pivot is not positive.
+CC_HD bool chol6(double V[21]) {
+  bool ok = true;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    double d = V[tri(6, i, i)];
+    CC_UNROLL
+    for (int k = 0; k < i; ++k) d -= V[tri(6, k, i)] * V[tri(6, k, i)];
+    ok = ok && (d > 0.0);
+    const double u = sqrt(d > 0.0 ? d : 1.0);
+    const double iu = 1.0 / u;
+    V[tri(6, i, i)] = u;
+    CC_UNROLL
+    for (int j = i + 1; j < 6; ++j) {
+      double s = V[tri(6, i, j)];
+      CC_UNROLL
+      for (int k = 0; k < i; ++k) s -= V[tri(6, k, i)] * V[tri(6, k, j)];
+      V[tri(6, i, j)] = s * iu;
+    }
+  }
+  return ok;
+}
+// y <- U^-T y   (forward substitution with the upper factor)
+CC_HD void chol6_fwd(const double U[21], double y[6]) {
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    double s = y[i];
+    CC_UNROLL
+    for (int k = 0; k < i; ++k) s -= U[tri(6, k, i)] * y[k];
+    y[i] = s / U[tri(6, i, i)];
+  }
+}
+// y <- U^-1 y   (back substitution)
+CC_HD void chol6_bwd(const double U[21], double y[6]) {
+  CC_UNROLL
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    CC_UNROLL
+    for (int k = i + 1; k < 6; ++k) s -= U[tri(6, i, k)] * y[k];
+    y[i] = s / U[tri(6, i, i)];
+  }
+}
+
+}  // namespace camcal

@@ -1,0 +1,225 @@
+"""Device-resident state of one process's share of the views and the stage
+calls on it (thin layer over the C ABI in include/camcal.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every number is
+produced by libcamcal.so.  One :class:`Engine` per process / per GPU.
+
+Layout (see include/camcal.h): views are sorted by corner count, placed in
+"slots", 64 slots form a tile (= one wavefront), points are packed so that
+corner k of a tile's 64 views is contiguous per component.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LANES = 64
+
+
+def make_layout(n_per_view: np.ndarray):
+    """Host-side slot/tile layout for views with the given corner counts.
+
+    Returns dict(slot_view i32[S], lane_n i32[S], tile_nmax i32[T],
+    tile_off i64[T], total_floats)."""
+    n = np.asarray(n_per_view, dtype=np.int64)
+    N = n.shape[0]
+    T = max((N + LANES - 1) // LANES, 1)
+    S = T * LANES
+    order = np.argsort(-n, kind="stable")
+    slot_view = np.full(S, -1, dtype=np.int32)
+    slot_view[:N] = order
+    lane_n = np.zeros(S, dtype=np.int32)
+    lane_n[:N] = n[order]
+    tile_nmax = lane_n.reshape(T, LANES).max(axis=1).astype(np.int32)
+    sizes = tile_nmax.astype(np.int64) * (5 * LANES)
+    tile_off = np.zeros(T, dtype=np.int64)
+    tile_off[1:] = np.cumsum(sizes)[:-1]
+    return dict(slot_view=slot_view, lane_n=lane_n, tile_nmax=tile_nmax, tile_off=tile_off,
+                total_floats=int(sizes.sum()), n_tiles=T, n_slots=S, n_views=N)
+
+
+class Engine:
+    """Packed observations + solver buffers of one rank.
+
+    Parameters
+    ----------
+    model : 0 pinhole / 1 fisheye
+    view_ptr : (N+1,) int64 CSR offsets
+    obj : (n_obs, 3) float32, img : (n_obs, 2) float32  (numpy or torch)
+    device : torch device; ``lib``: CamcalLib (default: the HIP build)
+    """
+
+    def __init__(self, model, view_ptr, obj, img, device, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        self.model = int(model)
+        self.device = torch.device(device)
+        if self.device.type != "cuda" and not self.lib.is_emulator:
+            raise _lib.CamcalError("the HIP library needs a cuda (ROCm) device; there is no CPU path")
+        self.NI = self.lib.camcal_n_intr(self.model)
+        if self.NI < 0:
+            raise _lib.CamcalError("unknown camera model")
+        self.glob_len = self.lib.camcal_glob_len(self.model)
+        self.schur_len = self.lib.camcal_schur_len(self.model)
+        view_ptr = np.asarray(torch.as_tensor(view_ptr).cpu().numpy(), dtype=np.int64)
+        n = np.diff(view_ptr)
+        self.n_views = int(n.shape[0])
+        self.n_obs = int(view_ptr[-1])
+        self.n_per_view = n
+        lay = make_layout(n)
+        self.layout = lay
+        dev = self.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.t_slot_view = torch.from_numpy(lay["slot_view"]).to(dev)
+        self.t_lane_n = torch.from_numpy(lay["lane_n"]).to(dev)
+        self.t_tile_nmax = torch.from_numpy(lay["tile_nmax"]).to(dev)
+        self.t_tile_off = torch.from_numpy(lay["tile_off"]).to(dev)
+        self.t_pts = torch.zeros(max(lay["total_floats"], 1), dtype=torch.float32, device=dev)
+        S = lay["n_slots"]
+        self.S = S
+        self.tiles = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off.data_ptr(),
+                                self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
+                                lay["n_tiles"], S)
+        # pack on the device
+        t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+        t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
+        if t_obj.shape[0] != self.n_obs or t_img.shape[0] != self.n_obs:
+            raise ValueError("view_ptr does not match the point arrays")
+        t_vp = torch.from_numpy(view_ptr).to(dev)
+        self._call("camcal_pack_tiles", t_obj.data_ptr(), t_img.data_ptr(), t_vp.data_ptr(),
+                   self.t_slot_view.data_ptr(), C.byref(self.tiles), self.t_pts.data_ptr(), self._stream())
+        self._sync()
+        del t_obj, t_img, t_vp
+        # solver buffers
+        self.intr = [torch.zeros(16, **f64), torch.zeros(16, **f64)]
+        self.pose = [torch.zeros(6, S, **f64), torch.zeros(6, S, **f64)]
+        self.pose[0][5] = 1.0
+        self.pose[1][5] = 1.0
+        self.V = torch.zeros(21, S, **f64)
+        self.W = torch.zeros(self.NI * 6, S, **f64)
+        self.g = torch.zeros(6, S, **f64)
+        self.glob = [torch.zeros(self.glob_len, **f64), torch.zeros(self.glob_len, **f64)]
+        self.schur = torch.zeros(self.schur_len, **f64)
+        self.dK = torch.zeros(16, **f64)
+        self.stats = torch.zeros(8, **f64)
+        self.norms = torch.zeros(2, **f64)
+        self.view_cost = torch.zeros(S, **f64)
+        self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model)), **f64)
+        self.status = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.iters = torch.zeros(S, dtype=torch.int32, device=dev)
+
+    # -- plumbing ------------------------------------------------------------
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _call(self, name, *args):
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                rc = getattr(self.lib, name)(*args)
+        else:
+            rc = getattr(self.lib, name)(*args)
+        self.lib.check(rc, name)
+
+    def _tp(self):
+        return C.byref(self.tiles)
+
+    # -- parameters ------------------------------------------------------------
+    def set_intr(self, which, values):
+        v = torch.zeros(16, dtype=torch.float64)
+        v[:self.NI] = torch.as_tensor(np.asarray(values, dtype=np.float64)[:self.NI])
+        self.intr[which].copy_(v.to(self.device))
+
+    def get_intr(self, which):
+        return self.intr[which][:self.NI].cpu().numpy().copy()
+
+    def set_poses(self, which, poses_view_order):
+        """poses (N, 6) in caller's view order -> slot order on the device."""
+        p = np.zeros((self.S, 6))
+        p[:, 5] = 1.0
+        sv = self.layout["slot_view"]
+        valid = sv >= 0
+        p[valid] = np.asarray(poses_view_order, dtype=np.float64)[sv[valid]]
+        self.pose[which].copy_(torch.from_numpy(np.ascontiguousarray(p.T)).to(self.device))
+
+    def get_poses(self, which):
+        """(N, 6) poses in the caller's view order."""
+        p = self.pose[which].cpu().numpy().T
+        sv = self.layout["slot_view"]
+        valid = sv >= 0
+        out = np.empty((self.n_views, 6))
+        out[sv[valid]] = p[valid]
+        return out
+
+    def slots_to_views(self, per_slot):
+        a = per_slot.cpu().numpy()
+        sv = self.layout["slot_view"]
+        valid = sv >= 0
+        out = np.empty((self.n_views,) + a.shape[1:], dtype=a.dtype)
+        out[sv[valid]] = a[valid]
+        return out
+
+    # -- stages ----------------------------------------------------------------
+    def pose_init(self, intr_idx, pose_idx):
+        self._call("camcal_pose_init", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), self.status.data_ptr(), self._stream())
+
+    def pose_refine(self, intr_idx, pose_idx, max_iter=20, tol=1e-10):
+        self._call("camcal_pose_refine", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), int(max_iter), float(tol), self.iters.data_ptr(),
+                   self._stream())
+
+    def intr_normal(self, intr_idx, pose_idx, glob_idx, with_normal=True, view_cost=False):
+        self._call("camcal_intr_normal", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), 1 if with_normal else 0,
+                   self.glob[glob_idx].data_ptr(),
+                   self.view_cost.data_ptr() if view_cost else None,
+                   self.scratch.data_ptr(), self._stream())
+
+    def view_blocks(self, intr_idx, pose_idx):
+        self._call("camcal_view_blocks", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), self.V.data_ptr(), self.W.data_ptr(),
+                   self.g.data_ptr(), self._stream())
+
+    def schur_complement(self, lam):
+        self._call("camcal_schur", self.model, self._tp(), self.V.data_ptr(), self.W.data_ptr(),
+                   self.g.data_ptr(), float(lam), self.schur.data_ptr(), self.scratch.data_ptr(),
+                   self._stream())
+
+    def solve_reduced(self, glob_idx, mask, lam, scale, intr_in, intr_out):
+        m = bytes(bytearray(int(bool(x)) for x in mask))
+        self._call("camcal_solve_reduced", self.model, self.glob[glob_idx].data_ptr(),
+                   self.schur.data_ptr(), m, float(lam), float(scale), self.intr[intr_in].data_ptr(),
+                   self.intr[intr_out].data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(),
+                   self._stream())
+
+    def backsub(self, lam, pose_in, pose_out):
+        self._call("camcal_backsub", self.model, self._tp(), self.V.data_ptr(), self.W.data_ptr(),
+                   self.g.data_ptr(), float(lam), self.dK.data_ptr(), self.pose[pose_in].data_ptr(),
+                   self.pose[pose_out].data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(),
+                   self._stream())
+
+    def normal_eq(self, intr_idx, pose_idx, glob_idx, lam):
+        """One full normal-equation evaluation (the benchmarked unit)."""
+        self._call("camcal_normal_eq", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), float(lam), self.V.data_ptr(), self.W.data_ptr(),
+                   self.g.data_ptr(), self.glob[glob_idx].data_ptr(), self.schur.data_ptr(),
+                   self.scratch.data_ptr(), self._stream())
+
+    def time_stage(self, stage, reps, lam=0.0):
+        """Average milliseconds per launch of one stage, HIP events on the
+        current stream (0 intr_normal, 1 view_blocks, 2 schur)."""
+        ms = C.c_float(0.0)
+        self._call("camcal_time_stage", int(stage), int(reps), self.model, self._tp(),
+                   self.intr[0].data_ptr(), self.pose[0].data_ptr(), float(lam), self.V.data_ptr(),
+                   self.W.data_ptr(), self.g.data_ptr(), self.glob[0].data_ptr(),
+                   self.schur.data_ptr(), self.scratch.data_ptr(), self._stream(), C.byref(ms))
+        return float(ms.value)

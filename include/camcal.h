@@ -1,0 +1,149 @@
+/* camcal.h -- C ABI of the MI355X calibration hot path (libcamcal.so).
+ *
+ * The reference (huangqi2002/CameraCalibration) has no FFI for this path: its
+ * boundary is the pair of Python calls
+ *     cv2.calibrateCamera(...)    server/aruco/camera_calib.py:153-156
+ *                                 server/internal/IntrinsicCalibration/intrinsicCalib.py:194-197,223-226
+ *     cv2.fisheye.calibrate(...)  server/aruco/camera_calib.py:74-77
+ *                                 server/internal/IntrinsicCalibration/intrinsicCalib.py:102-105,131-134
+ * whose arithmetic lives inside OpenCV.  cameracalibration_amd re-exports those
+ * two Python signatures and binds the entry points below
+ * with ctypes; each entry point is one stage of the solver that OpenCV runs
+ * inside those calls (stage <-> OpenCV routine given per function).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - model: 0 = pinhole [fx fy cx cy k1 k2 p1 p2 k3] (NI = 9)
+ *            1 = Kannala-Brandt fisheye [fx fy cx cy k1 k2 k3 k4] (NI = 8)
+ *   - residual e = projected - observed; doubles everywhere except the packed
+ *     float32 observations
+ *   - views are packed in tiles of 64 "slots" (one wavefront); slot s of tile T
+ *     is lane s%64.  Point c (X Y Z u v = 0..4) of corner k of that lane lives
+ *     at pts[tile_off[T] + (k*5 + c)*64 + lane].  lane_n[s] = corner count
+ *     (0 for padding slots), tile_nmax[T] = max over the tile.
+ *   - per-slot arrays are component-major: pose[c*n_slots + s], c = r0 r1 r2 t0 t1 t2;
+ *     V[e*n_slots + s] (21 upper-triangle entries of the 6x6 pose block),
+ *     W[(a*6 + c)*n_slots + s] (NI x 6), g[c*n_slots + s]
+ *   - all functions return 0 on success, a hipError_t (> 0) if a HIP call
+ *     failed, or a negative CAMCAL_E_* code for rejected arguments.
+ */
+#ifndef CAMCAL_H
+#define CAMCAL_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAMCAL_PINHOLE 0
+#define CAMCAL_FISHEYE 1
+
+#define CAMCAL_E_BADARG  (-1)
+#define CAMCAL_E_BADMODEL (-2)
+#define CAMCAL_E_TOOBIG  (-3)
+
+/* Packed observations of the views owned by this process (device pointers). */
+typedef struct camcal_tiles {
+  const float*   pts;        /* packed X Y Z u v, see above                    */
+  const int64_t* tile_off;   /* [n_tiles] offset of each tile in floats       */
+  const int32_t* tile_nmax;  /* [n_tiles]                                      */
+  const int32_t* lane_n;     /* [n_slots] corners per slot, 0 = padding        */
+  int32_t        n_tiles;
+  int64_t        n_slots;    /* == 64 * n_tiles                                */
+} camcal_tiles;
+
+/* Library version (major*10000 + minor*100 + patch). */
+int camcal_version(void);
+
+/* Number of doubles in the global normal-equation record of a model:
+ *   [ U (NI(NI+1)/2) | b (NI) | cost ]  ->  camcal_glob_len
+ *   [ C (NI(NI+1)/2) | d (NI) ]         ->  camcal_schur_len                  */
+int camcal_n_intr(int model);
+int camcal_glob_len(int model);
+int camcal_schur_len(int model);
+
+/* Doubles of scratch the reducing entry points need (partial sums of the
+ * launched wavefronts); depends only on the model. */
+int64_t camcal_scratch_len(int model);
+
+/* Gather cv2-style AoS points into tiles.  obj_xyz [n_obs][3] f32, img_uv
+ * [n_obs][2] f32, view_ptr [n_views+1] i64 (CSR), slot_view [n_slots] i32 =
+ * view index placed in each slot or -1.  Writes tiles->pts (caller-allocated,
+ * size = sum over tiles of 5*64*nmax floats).  Host-side counterpart of the
+ * float32 lists the reference hands to cv2 (camera_calib.py:70-75). */
+int camcal_pack_tiles(const float* obj_xyz, const float* img_uv, const int64_t* view_ptr,
+                      const int32_t* slot_view, const camcal_tiles* tiles, float* pts_out,
+                      void* stream);
+
+/* Per-view pose initialisation for planar Z = 0 boards (cv::internal::
+ * InitExtrinsics / cvFindExtrinsicCameraParams2 planar branch).  status[s] = 0
+ * ok, >0 degenerate view. */
+int camcal_pose_init(int model, const camcal_tiles* tiles, const double* intr, double* pose,
+                     int32_t* status, void* stream);
+
+/* Per-view Gauss-Newton pose refinement at fixed intrinsics
+ * (cv::internal::ComputeExtrinsicRefine; also used in place of the 6-dof
+ * CvLevMarq of cvFindExtrinsicCameraParams2).  iters[s] = steps taken. */
+int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr, double* pose,
+                       int max_iter, double tol, int32_t* iters, void* stream);
+
+/* Normal-equation evaluation, intrinsic part (cvCalibrateCamera2Internal's
+ * JtJ(0:NI,0:NI), JtErr(0:NI), errNorm; fisheye ComputeJacobians' A A^T, A e).
+ * with_normal = 0 computes the cost only (CvLevMarq CHECK_ERR pass).
+ * glob receives camcal_glob_len doubles; view_cost (optional, may be NULL)
+ * receives the sum of squared residuals of every slot. */
+int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
+                       const double* pose, int with_normal, double* glob, double* view_cost,
+                       double* scratch, void* stream);
+
+/* Normal-equation evaluation, per-view part: V = Je^T Je, W = Ji^T Je,
+ * g = Je^T e in Rodrigues coordinates (the B B^T, A B^T, B e blocks of
+ * ComputeJacobians; the JtJ(ext,ext), JtJ(0:NI,ext), JtErr(ext) blocks of
+ * cvCalibrateCamera2Internal). */
+int camcal_view_blocks(int model, const camcal_tiles* tiles, const double* intr,
+                       const double* pose, double* V, double* W, double* g, void* stream);
+
+/* Schur complement of the (damped) pose blocks onto the intrinsics:
+ * C = sum W V'^-1 W^T, d = sum W V'^-1 g with V' = V, diag*(1+lam).
+ * schur receives camcal_schur_len doubles. */
+int camcal_schur(int model, const camcal_tiles* tiles, const double* V, const double* W,
+                 const double* g, double lam, double* schur, double* scratch, void* stream);
+
+/* Reduced solve (U' - C) dK = b - d on the free intrinsics (mask[a] != 0),
+ * U' = U with diag*(1+lam);  intr_out = intr_in + scale*dK.
+ * (CvLevMarq::step on the eliminated system: scale = -1; fisheye::calibrate's
+ * `finalParam + alpha_smooth2*G`: scale = -alpha_smooth2, lam = 0.)
+ * stats[0] = ||scale*dK||^2, stats[1] = ||intr_in||^2,
+ * stats[2] = ||d(fx fy cx cy)||^2, stats[3] = ||(fx fy cx cy)_out||^2,
+ * stats[4] = 0 if the elimination met a non-positive pivot else 1. */
+int camcal_solve_reduced(int model, const double* glob, const double* schur,
+                         const uint8_t* mask_host, double lam, double scale,
+                         const double* intr_in, double* intr_out, double* dK, double* stats,
+                         void* stream);
+
+/* Back-substitution d_i = V'^-1 (g_i - W_i^T dK); pose_out = pose_in - d_i.
+ * norms[0] = sum ||d_i||^2, norms[1] = sum ||pose_in||^2 (the pose part of
+ * cvNorm(param, prevParam, CV_RELATIVE_L2) in CvLevMarq::updateAlt). */
+int camcal_backsub(int model, const camcal_tiles* tiles, const double* V, const double* W,
+                   const double* g, double lam, const double* dK, const double* pose_in,
+                   double* pose_out, double* norms, double* scratch, void* stream);
+
+/* One full normal-equation evaluation = camcal_intr_normal(with_normal=1) +
+ * camcal_view_blocks + camcal_schur, the unit the benchmark times. */
+int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr,
+                     const double* pose, double lam, double* V, double* W, double* g,
+                     double* glob, double* schur, double* scratch, void* stream);
+
+/* Timing helper for benchmarks: average duration in milliseconds of `reps`
+ * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,
+ * 2 = schur), measured with HIP events on `stream`. */
+int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
+                      const double* intr, const double* pose, double lam, double* V, double* W,
+                      double* g, double* glob, double* schur, double* scratch, void* stream,
+                      float* ms_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMCAL_H */
