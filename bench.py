@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the calibration hot path on MI355X.
+
+One "step" = one full normal-equation evaluation (projection + residual +
+analytic Jacobian + per-view blocks + Schur complement onto the intrinsics,
+plus -- on N > 1 GPUs -- the all-reduce of the small global record) over the
+rank's resident views.  Workload at every N: BASELINE.json config 5, the
+stress set of Kannala-Brandt fisheye views x 88 corners, ``--views`` views
+PER GPU (weak scaling, default 1,000,000 = the config's size on one GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from cameracalibration_amd import _lib, synth  # noqa: E402
+from cameracalibration_amd.engine import Engine  # noqa: E402
+
+# Algorithmic work model (BASELINE.md section 3 / SURVEY.md 8d; re-counted in DESIGN.md)
+FLOP_PER_OBS = {"fisheye": 605.0, "pinhole": 732.0}
+FLOP_PER_VIEW = 1200.0
+BYTES_PER_OBS = 20.0
+BYTES_PER_VIEW = 696.0
+PEAK_FP64_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 FMA lanes x 2 flop x 2.4 GHz (vector FP64)
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(seconds_target=12.0):
+    """Times the C oracle (oracle/normal_eq.c, a plain restatement of cv2's
+    per-view accumulation) on a bounded sample of the same workload."""
+    try:
+        from oracle import cport
+        nthreads = min(16, os.cpu_count() or 1)
+        n_views = 4000
+        P = synth.config("C5", n_views=n_views, device="cpu")
+        intr = P.intr_guess()
+        poses = P.poses_true.numpy()
+        obj, img = P.obj.numpy(), P.img.numpy()
+        cport.normal_eq(1, P.view_ptr, obj, img, intr, poses, nthreads=nthreads, want_blocks=False)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            cport.normal_eq(1, P.view_ptr, obj, img, intr, poses, nthreads=nthreads, want_blocks=False)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > seconds_target or reps >= 400:
+                break
+        return {"value": P.n_obs * reps / el, "unit": "corner-obs/s", "cores": nthreads, "kind": "port",
+                "sample": f"{reps} evaluations of {n_views} fisheye views x 88 corners (oracle/normal_eq.c, "
+                          f"OpenMP {nthreads} threads, {el:.1f} s)"}
+    except Exception as exc:  # the baseline is reported, never required
+        return {"value": None, "unit": "corner-obs/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=1_000_000, help="views per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    lib = _lib.load()
+    P = synth.config("C5", n_views=args.views, device=dev, seed=5 + rank)
+    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
+    n_obs, n_views = P.n_obs, P.n_views
+    E.set_intr(0, P.intr_guess())
+    # state of the solver at its first evaluation: poses initialised and
+    # refined per view at the guessed intrinsics
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    del P
+    torch.cuda.synchronize()
+
+    def step():
+        E.normal_eq(0, 0, 0, 0.0)
+        if world > 1:
+            dist.all_reduce(E.rec)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    # per-kernel durations (HIP events on the launch stream), rank 0
+    stage_ms = {}
+    if rank == 0:
+        for st, nm in ((0, "intr_normal"), (1, "view_blocks"), (2, "schur")):
+            E.time_stage(st, 3)
+            stage_ms[nm] = E.time_stage(st, max(args.steps, 10))
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        pass_ms = sum(stage_ms.values())
+        flops = FLOP_PER_OBS["fisheye"] * n_obs + FLOP_PER_VIEW * n_views
+        bytes_alg = BYTES_PER_OBS * n_obs + BYTES_PER_VIEW * n_views
+        ach_tf = flops / (pass_ms * 1e-3) * 1e-12
+        ach_gb = bytes_alg / (pass_ms * 1e-3) * 1e-9
+        # measured peaks on this device (BASELINE.md section 3 asks for both)
+        import ctypes as C
+        res = C.c_double(0.0)
+        probe = {}
+        buf = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        for kind, key in ((0, "fp64_fma_tflops"), (1, "hbm_read_gbs")):
+            rc = lib.camcal_peak_probe(kind, buf.data_ptr(), buf.numel(), 5,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(res))
+            probe[key] = float(res.value) if rc == 0 else None
+        del buf
+        out = {
+            "metric": "corner-obs/s for residual+Jacobian+Schur (one normal-equation evaluation)",
+            "value": world * n_obs * args.steps / el,
+            "unit": "corner-obs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"C5 stress: {n_views} Kannala-Brandt fisheye views x 88 corners per GPU "
+                                   f"({n_obs} corner observations per GPU), 8 intrinsics + 6 per view",
+                       "views_per_gpu": n_views, "obs_per_gpu": n_obs, "parallelism": f"views sharded x{world}"},
+            "roofline": {
+                "bound": "fp64-valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                "kernels_ms": stage_ms, "pass_ms": pass_ms,
+                "work_model": "605 flop/obs + 1200 flop/view (BASELINE.md section 3), whole J pass = "
+                              "k_intr_normal + k_view_blocks + k_schur",
+                "measured_peak_fp64_tflops": probe.get("fp64_fma_tflops"),
+                "frac_of_measured_peak": (ach_tf / probe["fp64_fma_tflops"]) if probe.get("fp64_fma_tflops") else None,
+            },
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": ach_gb / PEAK_HBM_GBS, "traffic": None,
+                             "measured_peak_read_gbs": probe.get("hbm_read_gbs"),
+                             "work_model": "20 B/obs + 696 B/view"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "camcal_normal_eq": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_float)]),
+    "camcal_peak_probe": (C.c_int, [_I, _P, C.c_int64, _I, _P, C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -262,6 +262,31 @@ __global__ __launch_bounds__(TPB) void k_pack_tiles(const float* __restrict__ ob
   }
 }
 
+// --- peak probes (bench only): dependent-free FP64 FMA stream, streaming read
+__global__ __launch_bounds__(TPB) void k_peak_fma(double* __restrict__ out, int iters, double a, double b) {
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = (double)(threadIdx.x + i) * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fma(x[i], a, b);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += x[i];
+  if (s == 123.456) out[0] = s;   // keeps the chain live, practically never taken
+}
+
+__global__ __launch_bounds__(TPB) void k_peak_read(const float4* __restrict__ in, size_t n4, float* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = in[i];
+    acc += v.x + v.y + v.z + v.w;
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
+
 inline int tiles_ok(const camcal_tiles* t) {
   if (!t || t->n_tiles <= 0 || t->n_slots != (int64_t)t->n_tiles * LANES) return 0;
   if (!t->tile_off || !t->tile_nmax || !t->lane_n) return 0;
@@ -439,10 +464,36 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   *ms_out_host = ms / reps;
   return rc;
+}
+
+int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream, double* result_host) {
+  if (!buf || bytes < 4096 || reps <= 0 || !result_host) return CAMCAL_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const int iters = 4096;
+  const int blocks = 256 * 8;
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0 warms up
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) {
+      if (kind == 0) hipLaunchKernelGGL(k_peak_fma, dim3(blocks), dim3(TPB), 0, s, (double*)buf, iters, 0.999999, 1e-7);
+      else hipLaunchKernelGGL(k_peak_read, dim3(256 * 16), dim3(TPB), 0, s, (const float4*)buf, (size_t)bytes / 16, (float*)buf);
+    }
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+  }
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (kind == 0) *result_host = 2.0 * 16.0 * iters * (double)blocks * TPB * reps / (ms * 1e-3) * 1e-12;   // TFLOP/s
+  else *result_host = (double)bytes * reps / (ms * 1e-3) * 1e-9;                                              // GB/s
+  return 0;
 }
 
 }  // extern "C"

@@ -101,8 +101,11 @@ class Engine:
         self.V = torch.zeros(21, S, **f64)
         self.W = torch.zeros(self.NI * 6, S, **f64)
         self.g = torch.zeros(6, S, **f64)
-        self.glob = [torch.zeros(self.glob_len, **f64), torch.zeros(self.glob_len, **f64)]
-        self.schur = torch.zeros(self.schur_len, **f64)
+        # [U|b|cost] and [C|d] of buffer 0 share one allocation so a full
+        # normal-equation evaluation needs a single all-reduce (self.rec)
+        self.rec = torch.zeros(self.glob_len + self.schur_len, **f64)
+        self.glob = [self.rec[:self.glob_len], torch.zeros(self.glob_len, **f64)]
+        self.schur = self.rec[self.glob_len:]
         self.dK = torch.zeros(16, **f64)
         self.stats = torch.zeros(8, **f64)
         self.norms = torch.zeros(2, **f64)

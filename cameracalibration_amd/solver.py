@@ -89,7 +89,7 @@ def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
         # accept: trial becomes current (buffers swap roles)
         E.intr[cur], E.intr[tri] = E.intr[tri], E.intr[cur]
         E.pose[cur], E.pose[tri] = E.pose[tri], E.pose[cur]
-        E.glob[cur], E.glob[tri] = E.glob[tri], E.glob[cur]
+        E.glob[cur].copy_(E.glob[tri])
         if log is not None:
             log.append(dict(iter=iters, err=err, rel=rel, lam_lg10=lam_lg10))
         if iters >= max_iter or rel < eps:

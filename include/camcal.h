@@ -143,6 +143,12 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
                       double* g, double* glob, double* schur, double* scratch, void* stream,
                       float* ms_out_host);
 
+/* Peak probes for the roofline report: kind 0 = dependent-free FP64 FMA stream
+ * (result TFLOP/s), kind 1 = streaming read of `bytes` from buf (result GB/s).
+ * buf: device scratch of at least `bytes` (>= 4096).  No reference counterpart. */
+int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream,
+                      double* result_host);
+
 #ifdef __cplusplus
 }
 #endif

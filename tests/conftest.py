@@ -1,0 +1,33 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMU_PATH = os.path.join(ROOT, "tests", "hostemu", "libcamcal_hostemu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """CPU lane emulator of libcamcal.so (test infrastructure, see tests/hostemu)."""
+    if not os.path.exists(EMU_PATH):
+        subprocess.run(["make", "-C", ROOT, "hostemu"], check=True)
+    from cameracalibration_amd import _lib
+    return _lib.load(EMU_PATH)
+
+
+@pytest.fixture(scope="session")
+def oracle_c():
+    path = os.path.join(ROOT, "oracle", "liboracle_c.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+    from oracle import cport
+    return cport
