@@ -46,7 +46,7 @@ def cpu_baseline(seconds_target=12.0):
     try:
         from oracle import cport
         nthreads = min(16, os.cpu_count() or 1)
-        n_views = 4000
+        n_views = 20000
         P = synth.config("C5", n_views=n_views, device="cpu")
         intr = P.intr_guess()
         poses = P.poses_true.numpy()
@@ -57,7 +57,7 @@ def cpu_baseline(seconds_target=12.0):
             cport.normal_eq(1, P.view_ptr, obj, img, intr, poses, nthreads=nthreads, want_blocks=False)
             reps += 1
             el = time.perf_counter() - t0
-            if el > seconds_target or reps >= 400:
+            if el > seconds_target or reps >= 100000:
                 break
         return {"value": P.n_obs * reps / el, "unit": "corner-obs/s", "cores": nthreads, "kind": "port",
                 "sample": f"{reps} evaluations of {n_views} fisheye views x 88 corners (oracle/normal_eq.c, "
