@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size 2 over gloo, views sharded by observation
+count, only the small global records all-reduced.  The per-lane compute is the
+CPU lane emulator (tests/hostemu); the sharding, the collectives and the
+drivers are the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "hostemu", "libcamcal_hostemu.so")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, model, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cameracalibration_amd as cc
+    from cameracalibration_amd import _lib, synth
+    from cameracalibration_amd.distributed import shard_lists
+    from cameracalibration_amd.solver import Comm
+    emu = _lib.load(EMU)
+    crit = (3, 1000, 1e-6)
+    if model == "fisheye":
+        P = synth.config("C3", n_views=90)
+        objs, imgs = P.as_lists()
+        o, i, (lo, hi) = shard_lists(objs, imgs, rank, world)
+        fl = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+        r = cc.fisheye.calibrate(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit,
+                                 _lib_override=emu, _device_override=torch.device("cpu"), _comm=Comm())
+    else:
+        P = synth.config("C1")
+        objs, imgs = P.as_lists()
+        o, i, (lo, hi) = shard_lists(objs, imgs, rank, world)
+        r = cc.calibrateCamera(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1, criteria=crit,
+                               _lib_override=emu, _device_override=torch.device("cpu"), _comm=Comm())
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), rms=r[0], K=r[1], D=r[2], rv=np.hstack(r[3]).T,
+             tv=np.hstack(r[4]).T, lo=lo, hi=hi)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["fisheye", "pinhole"])
+def test_two_rank_solve_equals_single_rank(model, emu, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), model, str(tmp_path)), nprocs=world, join=True)
+    import cameracalibration_amd as cc
+    from cameracalibration_amd import synth
+    crit = (3, 1000, 1e-6)
+    if model == "fisheye":
+        P = synth.config("C3", n_views=90)
+        objs, imgs = P.as_lists()
+        fl = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+        ref = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl,
+                                   criteria=crit, _lib_override=emu, _device_override=torch.device("cpu"))
+    else:
+        P = synth.config("C1")
+        objs, imgs = P.as_lists()
+        ref = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1,
+                                 criteria=crit, _lib_override=emu, _device_override=torch.device("cpu"))
+    parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    assert parts[0]["hi"] == parts[1]["lo"] and parts[0]["lo"] == 0 and parts[1]["hi"] == len(objs)
+    for p in parts:                                   # every rank holds the same global answer
+        assert abs(float(p["rms"]) - ref[0]) < 1e-10
+        assert np.allclose(p["K"], ref[1], rtol=1e-10) and np.allclose(p["D"], ref[2], rtol=1e-8, atol=1e-13)
+    rv = np.concatenate([p["rv"] for p in parts])
+    tv = np.concatenate([p["tv"] for p in parts])
+    assert np.allclose(rv, np.hstack(ref[3]).T, atol=1e-9) and np.allclose(tv, np.hstack(ref[4]).T, atol=1e-7)

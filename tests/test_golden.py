@@ -1,0 +1,67 @@
+"""Golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from
+the cv2-faithful dense oracle): the O(N) oracle and the product's host logic on
+the CPU lane emulator reproduce them.  The GPU tier repeats this through the
+HIP library (tests/test_gpu_parity.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cameracalibration_amd as cc
+from oracle import cvcalib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def load(path):
+    z = np.load(path, allow_pickle=False)
+    vp = z["view_ptr"]
+    objs = [z["obj"][vp[k]:vp[k + 1]].reshape(-1, 1, 3) for k in range(len(vp) - 1)]
+    imgs = [z["img"][vp[k]:vp[k + 1]].reshape(-1, 1, 2) for k in range(len(vp) - 1)]
+    crit = (int(z["criteria"][0]), int(z["criteria"][1]), float(z["criteria"][2]))
+    return z, objs, imgs, crit
+
+
+def check(z, res, iters=None):
+    rms, K, D, rv, tv = res[:5]
+    rv = np.hstack(rv).T if isinstance(rv, tuple) else rv
+    tv = np.hstack(tv).T if isinstance(tv, tuple) else tv
+    assert abs(rms - float(z["rms"])) < 1e-9                      # north star: 1e-6 px
+    assert np.allclose(K, z["K"], rtol=1e-8, atol=0)              # north star: 1e-6 relative
+    assert np.allclose(D, z["D"], rtol=1e-6, atol=1e-10)
+    assert np.allclose(rv, z["rvecs"], atol=1e-8) and np.allclose(tv, z["tvecs"], atol=1e-6)
+    if iters is not None:
+        assert iters == int(z["iters"])
+
+
+def test_fixtures_present():
+    assert len(FILES) >= 4
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_schur_reproduces_golden(path):
+    z, objs, imgs, crit = load(path)
+    size = tuple(int(v) for v in z["image_size"])
+    if str(z["model"]) == "pinhole":
+        r = O.calibrate_camera(objs, imgs, size, z["K_guess"], z["D_guess"], flags=int(z["flags"]), criteria=crit,
+                               solver="schur")
+    else:
+        r = O.fisheye_calibrate(objs, imgs, size, z["K_guess"], z["D_guess"], flags=int(z["flags"]), criteria=crit,
+                                solver="schur")
+    check(z, r, r[5]["iters"])
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_host_logic_on_emulator_reproduces_golden(path, emu):
+    z, objs, imgs, crit = load(path)
+    size = tuple(int(v) for v in z["image_size"])
+    info = {}
+    kw = dict(flags=int(z["flags"]), criteria=crit, _lib_override=emu, _device_override=torch.device("cpu"), _info=info)
+    if str(z["model"]) == "pinhole":
+        r = cc.calibrateCamera(objs, imgs, size, z["K_guess"].copy(), z["D_guess"].copy(), **kw)
+    else:
+        r = cc.fisheye.calibrate(objs, imgs, size, z["K_guess"].copy(), z["D_guess"].copy(), **kw)
+    check(z, r, info["iters"])

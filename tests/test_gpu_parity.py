@@ -1,0 +1,249 @@
+"""Parity tests proper: the HIP library (through the C ABI / the drop-in API)
+against the oracle on the same seeded inputs, against the committed golden
+vectors, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Bar: fp64 work, so agreement to round-off of the differently
+ordered sums: blocks 1e-11 relative; solver outputs rms 1e-9 px, K 1e-8
+relative, D 1e-6 relative (north star: 1e-6 px / 1e-6 relative)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cameracalibration_amd as cc
+from cameracalibration_amd import _lib, synth
+from cameracalibration_amd.engine import Engine
+from oracle import cvcalib as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+CRIT = (3, 1000, 1e-6)
+FE = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tier needs a ROCm device"
+    lib = _lib.load()
+    assert not lib.is_emulator and lib.camcal_version() > 0      # the HIP build, not the emulator
+    return torch.device("cuda:0")
+
+
+def sym(tri, n):
+    U = np.zeros((n, n))
+    U[np.triu_indices(n)] = tri
+    return U + U.T - np.diag(np.diag(U))
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("name,model,mid,nv", [("C1", "pinhole", 0, 20), ("C2", "fisheye", 1, 500),
+                                               ("C3", "fisheye", 1, 700), ("C3", "fisheye", 1, 1)])
+def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv):
+    P = synth.config(name, n_views=nv)
+    objs, imgs = P.as_lists()
+    views = O.Views(objs, imgs)
+    g, poses = P.intr_guess(), P.poses_true.numpy()
+    E = Engine(mid, P.view_ptr, P.obj, P.img, dev)
+    E.set_intr(0, g)
+    E.set_poses(0, poses)
+    lam = 1e-3
+    E.normal_eq(0, 0, 0, lam)
+    blk = O.normal_blocks(model, views, g, poses)
+    NI, nu = E.NI, E.NI * (E.NI + 1) // 2
+    G = E.glob[0].cpu().numpy()
+    assert rel(sym(G[:nu], NI), blk["U"]) < 1e-11 and rel(G[nu:nu + NI], blk["b"]) < 1e-10
+    assert abs(G[-1] / blk["cost"] - 1) < 1e-12
+    i6 = np.triu_indices(6)
+    assert rel(E.slots_to_views(E.V.T), blk["V"][:, i6[0], i6[1]]) < 1e-11
+    assert rel(E.slots_to_views(E.W.T).reshape(-1, NI, 6), blk["W"]) < 1e-11
+    assert rel(E.slots_to_views(E.g.T), blk["g"]) < 1e-10
+    # Schur complement, reduced solve and back-substitution against the oracle's elimination
+    mask = np.ones(NI, dtype=bool)
+    dK, di = O._schur_step(blk, lam, mask, damp=True)
+    S = E.schur.cpu().numpy()
+    Vd = blk["V"].copy()
+    d6 = np.arange(6)
+    Vd[:, d6, d6] *= 1 + lam
+    Y = np.linalg.solve(Vd, np.concatenate([blk["W"].transpose(0, 2, 1), blk["g"][..., None]], axis=2))
+    C = np.einsum("bik,bkj->ij", blk["W"], Y[..., :-1])
+    d = np.einsum("bik,bk->i", blk["W"], Y[..., -1])
+    assert rel(sym(S[:nu], NI), C) < 1e-10 and rel(S[nu:], d) < 1e-10
+    if nv >= 20:
+        E.solve_reduced(0, mask, lam, -1.0, 0, 1)
+        E.backsub(lam, 0, 1)
+        # the reduced system is ill-conditioned in k3/k4; compare the step in the metric of the problem
+        got = E.dK[:NI].cpu().numpy()
+        sc = np.sqrt(np.diag(blk["U"]))
+        assert np.abs((got - dK) * sc).max() < 1e-6 * np.abs(dK * sc).max()
+        assert np.allclose(E.get_poses(1), poses - di, rtol=1e-7, atol=1e-7)
+        nr = E.norms.cpu().numpy()
+        assert abs(nr[1] / (poses ** 2).sum() - 1) < 1e-12
+
+
+def test_cost_only_and_per_view_cost(dev):
+    P = synth.config("C3", n_views=300)
+    objs, imgs = P.as_lists()
+    views = O.Views(objs, imgs)
+    g, poses = P.intr_guess(), P.poses_true.numpy()
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    E.set_intr(0, g)
+    E.set_poses(0, poses)
+    E.intr_normal(0, 0, 1, with_normal=False, view_cost=True)
+    assert abs(E.glob[1][-1].item() / O.reproj_cost("fisheye", views, g, poses) - 1) < 1e-12
+    vc = E.slots_to_views(E.view_cost)
+    want = O.per_view_reproj_err("fisheye", views, g, poses)          # ||e||/n
+    assert np.allclose(np.sqrt(vc) / views.n, want, rtol=1e-11)
+
+
+def test_pose_init_and_refine_match_oracle(dev):
+    P = synth.config("C2", n_views=200)
+    objs, imgs = P.as_lists()
+    views = O.Views(objs, imgs)
+    g = P.intr_guess()
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    E.set_intr(0, g)
+    E.pose_init(0, 0)
+    assert int(E.status.abs().sum().item()) == 0
+    want0 = np.stack([O.init_extrinsics_fisheye(o, i, g) for o, i in zip(views.obj[:40], views.img[:40])])
+    assert np.allclose(E.get_poses(0)[:40], want0, rtol=1e-6, atol=1e-6)
+    p0 = E.get_poses(0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    want, iters = O.refine_poses_fisheye_batched(views, p0, g)
+    assert np.allclose(E.get_poses(0), want, rtol=1e-9, atol=1e-8)
+    assert (E.slots_to_views(E.iters) == iters).mean() > 0.95           # same stopping rule
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_golden_vectors_through_drop_in_api(dev, path):
+    from tests.test_golden import check, load
+    z, objs, imgs, crit = load(path)
+    size = tuple(int(v) for v in z["image_size"])
+    info = {}
+    if str(z["model"]) == "pinhole":
+        r = cc.calibrateCamera(objs, imgs, size, z["K_guess"].copy(), z["D_guess"].copy(), flags=int(z["flags"]),
+                               criteria=crit, _info=info)
+    else:
+        r = cc.fisheye.calibrate(objs, imgs, size, z["K_guess"].copy(), z["D_guess"].copy(), flags=int(z["flags"]),
+                                 criteria=crit, _info=info)
+    check(z, r, info["iters"])
+
+
+def test_config1_pinhole_vs_oracle(dev):
+    P = synth.config("C1")
+    objs, imgs = P.as_lists()
+    K, D = P.K_guess.copy(), P.D_guess.copy()
+    r = cc.calibrateCamera(objs, imgs, P.image_size, K, D, flags=cc.CALIB_USE_INTRINSIC_GUESS, criteria=CRIT)
+    o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=1, criteria=CRIT, solver="dense")
+    assert r[1] is K and abs(r[0] - o[0]) < 1e-9
+    assert np.allclose(K, o[1], rtol=1e-8) and np.allclose(D, o[2], rtol=1e-6, atol=1e-10)
+
+
+def test_config2_fisheye_500_views_vs_oracle(dev):
+    P = synth.config("C2")
+    objs, imgs = P.as_lists()
+    info = {}
+    r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE, criteria=CRIT,
+                             _info=info)
+    o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=FE, criteria=CRIT, solver="schur")
+    assert info["iters"] == o[5]["iters"] and abs(r[0] - o[0]) < 1e-9
+    assert np.allclose(r[1], o[1], rtol=1e-9) and np.allclose(r[2], o[2], rtol=1e-6, atol=1e-11)
+    assert np.allclose(np.hstack(r[3]).T, o[3], atol=1e-8) and np.allclose(np.hstack(r[4]).T, o[4], atol=1e-6)
+    # and the answer is the truth to within the noise
+    assert np.allclose(r[1][[0, 1, 0, 1], [0, 1, 2, 2]], P.K_true, rtol=2e-3)
+
+
+def test_config3_ragged_subsample_vs_oracle(dev):
+    P = synth.config("C3", n_views=2000)
+    objs, imgs = P.as_lists()
+    r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE, criteria=CRIT)
+    o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=FE, criteria=CRIT, solver="schur")
+    assert abs(r[0] - o[0]) < 1e-9 and np.allclose(r[1], o[1], rtol=1e-9) and np.allclose(r[2], o[2], rtol=1e-6, atol=1e-11)
+
+
+def test_noise_free_ground_truth_on_gpu(dev):
+    P = synth.config("C2", n_views=300, noise=0.0)
+    objs, imgs = P.as_lists()
+    r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE,
+                             criteria=(3, 200, 1e-12))
+    assert r[0] < 2e-4                                   # float32 pixel rounding floor
+    assert np.allclose(r[1][[0, 1, 0, 1], [0, 1, 2, 2]], P.K_true, rtol=1e-6)
+    assert np.allclose(r[2].ravel(), P.D_true, atol=1e-5)
+
+
+def _engine_for(P, dev):
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    E.set_intr(0, P.intr_guess())
+    S, N = E.S, P.n_views
+    pose = torch.zeros(6, S, dtype=torch.float64, device=dev)
+    pose[5] = 1.0
+    sv = torch.from_numpy(E.layout["slot_view"].astype(np.int64)).to(dev)
+    valid = sv >= 0
+    pose[:, valid] = P.poses_true.to(dev).T[:, sv[valid]]
+    E.pose[0].copy_(pose)
+    return E
+
+
+def test_full_size_properties_config3_and_5(dev):
+    """Size-independent properties at BASELINE sizes (the oracle cannot run
+    these in seconds): (1) additivity -- the records of the full set equal the
+    sum of the records of two halves; (2) view-order invariance; (3) the C
+    oracle agrees on a 4000-view sample of the same set; (4) at the true
+    parameters cost = sigma^2 * 2 * n_obs within sampling error."""
+    for name, nv in (("C3", 100_000), ("C5", 1_000_000)):
+        P = synth.config(name, n_views=nv, device=dev)
+        E = _engine_for(P, dev)
+        E.set_intr(0, P.intr_true())
+        E.normal_eq(0, 0, 0, 0.0)
+        full = E.rec.cpu().numpy().copy()
+        sigma2 = full[E.glob_len - 1] / (2 * P.n_obs)
+        assert abs(sigma2 - 0.04) < 0.04 * 0.01 + 1e-5            # noise 0.2 px (+ float32 rounding)
+        vp = P.view_ptr
+        h = nv // 2
+        parts = []
+        for lo, hi in ((0, h), (h, nv)):
+            Q = synth.Problem(P.model, P.image_size, P.K_true, P.D_true, P.K_guess, P.D_guess,
+                              vp[lo:hi + 1] - vp[lo], P.obj[vp[lo]:vp[hi]], P.img[vp[lo]:vp[hi]],
+                              P.poses_true[lo:hi])
+            Eh = _engine_for(Q, dev)
+            Eh.set_intr(0, P.intr_true())
+            Eh.normal_eq(0, 0, 0, 0.0)
+            parts.append(Eh.rec.cpu().numpy().copy())
+            del Eh, Q
+        assert np.allclose(parts[0] + parts[1], full, rtol=1e-9, atol=1e-6 * np.abs(full).max())
+        # C oracle on a sample
+        from oracle import cport
+        ns = 4000
+        r = cport.normal_eq(1, (vp[:ns + 1]).copy(), P.obj[:vp[ns]].cpu().numpy(), P.img[:vp[ns]].cpu().numpy(),
+                            P.intr_true(), P.poses_true[:ns].cpu().numpy(), nthreads=8, want_blocks=False)
+        Q = synth.Problem(P.model, P.image_size, P.K_true, P.D_true, P.K_guess, P.D_guess, vp[:ns + 1].copy(),
+                          P.obj[:vp[ns]], P.img[:vp[ns]], P.poses_true[:ns])
+        Es = _engine_for(Q, dev)
+        Es.set_intr(0, P.intr_true())
+        Es.normal_eq(0, 0, 0, 0.0)
+        G = Es.rec.cpu().numpy()
+        nu = 36
+        assert rel(sym(G[:nu], 8), r["U"]) < 1e-11 and rel(G[nu:nu + 8], r["b"]) < 1e-9
+        assert rel(sym(G[45:45 + nu], 8), r["C"]) < 1e-10 and rel(G[45 + nu:], r["d"]) < 1e-9
+        del E, Es, P, Q
+        torch.cuda.empty_cache()
+
+
+def test_large_solve_recovers_truth(dev):
+    """Config 3 at full size through the whole solver: 100k ragged views."""
+    P = synth.config("C3", n_views=100_000, device=dev)
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    from cameracalibration_amd import solver
+    E.set_intr(0, P.intr_guess())
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), CRIT)
+    intr = E.get_intr(0)
+    rms = np.sqrt(cost / P.n_obs)
+    assert abs(rms - 0.2 * np.sqrt(2)) < 2e-3
+    assert np.allclose(intr[:4], P.K_true, rtol=1e-4) and np.allclose(intr[4:], P.D_true, atol=2e-4)

@@ -1,0 +1,204 @@
+"""Host logic of the drop-in (no GPU): layout/packing, cv2-compatible argument
+handling, and the solver drivers run against the CPU lane emulator (the same
+per-lane code the HIP kernels execute) and checked with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import cameracalibration_amd as cc
+from cameracalibration_amd import _lib, api, synth
+from cameracalibration_amd.engine import Engine, make_layout
+from cameracalibration_amd.distributed import shard_ranges
+from oracle import cvcalib as O
+
+CPU = torch.device("cpu")
+CRIT = (cc.TERM_CRITERIA_EPS + cc.TERM_CRITERIA_COUNT, 1000, 1e-6)
+FE = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+
+
+def test_constants_match_cv2():
+    assert cc.CALIB_USE_INTRINSIC_GUESS == 1 and cc.TERM_CRITERIA_COUNT == 1 and cc.TERM_CRITERIA_EPS == 2
+    f = cc.fisheye
+    assert (f.CALIB_USE_INTRINSIC_GUESS, f.CALIB_RECOMPUTE_EXTRINSIC, f.CALIB_CHECK_COND, f.CALIB_FIX_SKEW) == (1, 2, 4, 8)
+    assert (f.CALIB_FIX_K1, f.CALIB_FIX_K2, f.CALIB_FIX_K3, f.CALIB_FIX_K4) == (16, 32, 64, 128)
+    assert f.CALIB_FIX_PRINCIPAL_POINT == 512 and f.CALIB_FIX_FOCAL_LENGTH == 2048
+    assert cc.CALIB_FIX_K3 == 128 and cc.CALIB_RATIONAL_MODEL == 16384 and cc.CALIB_FIX_TANGENT_DIST == 2097152
+
+
+def test_layout_ragged():
+    n = np.array([13, 63, 40, 13, 57] * 30)
+    lay = make_layout(n)
+    assert lay["n_tiles"] == 3 and lay["n_slots"] == 192
+    assert (np.sort(lay["slot_view"][:150]) == np.arange(150)).all() and (lay["slot_view"][150:] == -1).all()
+    assert (np.diff(lay["lane_n"][:150]) <= 0).all()            # sorted, longest first
+    assert (lay["tile_nmax"] == [63, 40, 13]).all()
+    assert lay["total_floats"] == 5 * 64 * (63 + 40 + 13)
+
+
+def test_pack_tiles_places_every_point(emu):
+    P = synth.config("C3", n_views=100)
+    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, CPU, lib=emu)
+    pts = E.t_pts.numpy()
+    lay = E.layout
+    obj, img = P.obj.numpy(), P.img.numpy()
+    for slot in (0, 17, 63, 64, 99):
+        v = lay["slot_view"][slot]
+        tile, lane = divmod(slot, 64)
+        for k in (0, lay["lane_n"][slot] - 1):
+            base = lay["tile_off"][tile] + k * 5 * 64 + lane
+            got = pts[base + 64 * np.arange(5)]
+            want = np.concatenate([obj[P.view_ptr[v] + k], img[P.view_ptr[v] + k]])
+            assert (got == want).all()
+
+
+def test_shard_ranges_balance_and_cover():
+    n = np.random.default_rng(0).integers(13, 64, 1000)
+    for w in (1, 2, 4, 8):
+        r = shard_ranges(n, w)
+        assert r[0][0] == 0 and r[-1][1] == 1000 and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        loads = [n[a:b].sum() for a, b in r]
+        assert max(loads) - min(loads) <= 2 * 63
+
+
+def _emu_kw(emu):
+    return dict(_lib_override=emu, _device_override=CPU)
+
+
+def test_calibrate_camera_signature_and_inplace(emu):
+    P = synth.config("C1")
+    objs, imgs = P.as_lists()
+    K, D = P.K_guess.copy(), P.D_guess.copy()
+    out = cc.calibrateCamera(objs, imgs, P.image_size, K, D, flags=cc.CALIB_USE_INTRINSIC_GUESS, criteria=CRIT,
+                             **_emu_kw(emu))
+    rms, Ko, Do, rv, tv = out
+    assert isinstance(rms, float) and Ko is K and Do is D          # written in place and returned
+    assert Do.shape == (5, 1) and Ko.shape == (3, 3) and Ko[0, 1] == 0 and Ko[2, 2] == 1
+    assert isinstance(rv, tuple) and len(rv) == 20 and rv[0].shape == (3, 1) and tv[0].dtype == np.float64
+    assert not np.allclose(K, P.K_guess)
+    o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=1, criteria=CRIT, solver="dense")
+    assert abs(rms - o[0]) < 1e-9
+    assert np.allclose(K, o[1], rtol=1e-8) and np.allclose(D, o[2], rtol=1e-6, atol=1e-10)
+
+
+def test_fisheye_matches_cv2_faithful_oracle(emu):
+    P = synth.config("C2", n_views=30)
+    objs, imgs = P.as_lists()
+    K, D = P.K_guess.copy(), P.D_guess.copy()
+    info = {}
+    rms, Ko, Do, rv, tv = cc.fisheye.calibrate(objs, imgs, P.image_size, K, D, flags=FE, criteria=CRIT,
+                                               _info=info, **_emu_kw(emu))
+    o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=FE, criteria=CRIT, solver="dense")
+    assert info["iters"] == o[5]["iters"]
+    assert Do.shape == (4, 1) and Ko is K
+    assert abs(rms - o[0]) < 1e-9
+    assert np.allclose(Ko, o[1], rtol=1e-9) and np.allclose(Do, o[2], rtol=1e-6, atol=1e-11)
+    assert np.allclose(np.hstack(rv).T, o[3], atol=1e-8) and np.allclose(np.hstack(tv).T, o[4], atol=1e-6)
+
+
+def test_ragged_views_fisheye(emu):
+    P = synth.config("C3", n_views=150)
+    objs, imgs = P.as_lists()
+    rms, K, D, rv, tv = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(),
+                                             flags=FE, criteria=CRIT, **_emu_kw(emu))
+    o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=FE, criteria=CRIT, solver="schur")
+    assert abs(rms - o[0]) < 1e-9 and np.allclose(K, o[1], rtol=1e-9) and np.allclose(D, o[2], rtol=1e-6, atol=1e-11)
+    assert np.allclose(np.hstack(rv).T, o[3], atol=1e-8)
+
+
+def test_refine_call_with_10_iterations(emu):
+    """intrinsicCalib.py:131-134 / :223-226: warm-started 10-iteration calls."""
+    P = synth.config("C2", n_views=20)
+    objs, imgs = P.as_lists()
+    crit = (3, 10, 1e-6)
+    r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE, criteria=crit,
+                             **_emu_kw(emu))
+    o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=FE, criteria=crit, solver="schur")
+    assert np.allclose(r[1], o[1], rtol=1e-10)
+
+
+def test_fix_flags(emu):
+    P = synth.config("C1")
+    objs, imgs = P.as_lists()
+    fl = cc.CALIB_USE_INTRINSIC_GUESS | cc.CALIB_FIX_PRINCIPAL_POINT | cc.CALIB_FIX_K3
+    K, D = P.K_guess.copy(), P.D_guess.copy()
+    rms, Ko, Do, _, _ = cc.calibrateCamera(objs, imgs, P.image_size, K, D, flags=fl, criteria=CRIT, **_emu_kw(emu))
+    assert Ko[0, 2] == P.K_guess[0, 2] and Ko[1, 2] == P.K_guess[1, 2] and Do[4, 0] == P.D_guess[4, 0]
+    o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=fl, criteria=CRIT, solver="dense")
+    assert np.allclose(Ko, o[1], rtol=1e-8) and abs(rms - o[0]) < 1e-9
+    P = synth.config("C2", n_views=20)
+    objs, imgs = P.as_lists()
+    fl = FE | cc.fisheye.CALIB_FIX_K4 | cc.fisheye.CALIB_FIX_FOCAL_LENGTH
+    rms, Ko, Do, _, _ = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl,
+                                             criteria=CRIT, **_emu_kw(emu))
+    assert Do[3, 0] == 0.0 and Ko[0, 0] == P.K_guess[0, 0]
+    o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=fl, criteria=CRIT, solver="schur")
+    assert np.allclose(Ko, o[1], rtol=1e-9) and np.allclose(Do, o[2], atol=1e-11)
+
+
+def test_errors_like_cv2(emu):
+    P = synth.config("C1")
+    objs, imgs = P.as_lists()
+    kw = dict(flags=1, criteria=CRIT, **_emu_kw(emu))
+    with pytest.raises(cc.error):
+        cc.calibrateCamera(objs, imgs[:-1], P.image_size, P.K_guess.copy(), P.D_guess.copy(), **kw)
+    with pytest.raises(cc.error):
+        cc.calibrateCamera([], [], P.image_size, P.K_guess.copy(), P.D_guess.copy(), **kw)
+    bad = [o.copy() for o in objs]
+    bad[0] = bad[0][:3]
+    with pytest.raises(cc.error):
+        cc.calibrateCamera(bad, [imgs[0][:3]] + imgs[1:], P.image_size, P.K_guess.copy(), P.D_guess.copy(), **kw)
+    K = P.K_guess.copy(); K[0, 0] = -1
+    with pytest.raises(cc.error):
+        cc.calibrateCamera(objs, imgs, P.image_size, K, P.D_guess.copy(), **kw)
+    K = P.K_guess.copy(); K[0, 2] = 5000
+    with pytest.raises(cc.error):
+        cc.calibrateCamera(objs, imgs, P.image_size, K, P.D_guess.copy(), **kw)
+    K = P.K_guess.copy(); K[0, 1] = 0.5
+    with pytest.raises(cc.error):
+        cc.calibrateCamera(objs, imgs, P.image_size, K, P.D_guess.copy(), **kw)
+    with pytest.raises(cc.error):
+        cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=0, criteria=CRIT,
+                           **_emu_kw(emu))
+    with pytest.raises(cc.error):
+        cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), np.zeros((5, 1)), flags=FE, criteria=CRIT,
+                             **_emu_kw(emu))
+    with pytest.raises(cc.error):
+        cc.fisheye.calibrate(objs, imgs, P.image_size, None, None, flags=FE, criteria=CRIT, **_emu_kw(emu))
+
+
+def test_no_cpu_fallback_in_product():
+    """Without a ROCm device the drop-in refuses to run instead of falling back."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    P = synth.config("C1")
+    objs, imgs = P.as_lists()
+    with pytest.raises(_lib.CamcalError):
+        cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1, criteria=CRIT)
+    with pytest.raises(_lib.CamcalError):
+        Engine(0, P.view_ptr, P.obj, P.img, CPU)            # HIP library + cpu tensor
+    with pytest.raises(_lib.CamcalError):
+        _lib.CamcalLib("/nonexistent/libcamcal.so")
+
+
+def test_pose_init_lands_in_basin(emu):
+    """Homography initialisation + refinement reaches the oracle's per-view optimum."""
+    for name, mid, model in (("C1", 0, "pinhole"), ("C2", 1, "fisheye")):
+        P = synth.config(name, n_views=24)
+        objs, imgs = P.as_lists()
+        views = O.Views(objs, imgs)
+        E = Engine(mid, P.view_ptr, P.obj, P.img, CPU, lib=emu)
+        g = P.intr_guess()
+        E.set_intr(0, g)
+        E.pose_init(0, 0)
+        assert int(E.status.abs().sum()) == 0
+        p0 = E.get_poses(0)
+        if model == "fisheye":
+            want0 = np.stack([O.init_extrinsics_fisheye(o, i, g) for o, i in zip(views.obj, views.img)])
+            assert np.allclose(p0, want0, rtol=1e-6, atol=1e-6)
+            E.pose_refine(0, 0, 20, 1e-10)
+            want, _ = O.refine_poses_fisheye_batched(views, want0, g)
+            assert np.allclose(E.get_poses(0), want, rtol=1e-9, atol=1e-8)
+        else:
+            E.pose_refine(0, 0, 20, 1e-10)
+            want = np.stack([O.find_extrinsics_pinhole(o, i, g, max_iter=200) for o, i in zip(views.obj, views.img)])
+            assert np.allclose(E.get_poses(0), want, rtol=1e-5, atol=1e-4)
