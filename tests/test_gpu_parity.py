@@ -245,5 +245,7 @@ def test_large_solve_recovers_truth(dev):
     cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), CRIT)
     intr = E.get_intr(0)
     rms = np.sqrt(cost / P.n_obs)
-    assert abs(rms - 0.2 * np.sqrt(2)) < 2e-3
+    # least squares absorbs 6 dof per view + 8 global: E[cost] = sigma^2 (2 n_obs - 6 N - 8)
+    want = 0.2 * np.sqrt((2 * P.n_obs - 6 * P.n_views - 8) / P.n_obs)
+    assert abs(rms - want) < 1e-3
     assert np.allclose(intr[:4], P.K_true, rtol=1e-4) and np.allclose(intr[4:], P.D_true, atol=2e-4)
