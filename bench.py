@@ -99,7 +99,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        E.normal_eq(0, 0, 0, 0.0)
+        E.normal_eq(0, 0, 0.0)
         if world > 1:
             dist.all_reduce(E.rec)
 

@@ -138,6 +138,69 @@ __global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const doubl
   }
 }
 
+// Fused normal-equation evaluation: U, b, cost + per-view blocks + Schur
+// complement in one pass over the points.  One tile per wavefront; the wave's
+// partial record [U|b|cost|C|d] goes to scratch[i][tile] (second stage sums).
+template <int MODEL, bool WRITE_BLOCKS>
+__global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const double* __restrict__ intr,
+                                                      const double* __restrict__ pose, double lam,
+                                                      double* __restrict__ Vb, double* __restrict__ Wb,
+                                                      double* __restrict__ gb, double* __restrict__ scratch,
+                                                      int scratch_stride) {
+  constexpr int NI = MT<MODEL>::NI;
+  constexpr int NG = IntrAcc<MODEL>::NV;
+  constexpr int NS = trisz(NI) + NI;
+  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (tile >= t.n_tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
+  double I[NI], p[6];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, slot, p);
+  const LaneTile tv = lane_tile(t, tile, lane);
+  ViewAcc<MODEL> acc;
+  IntrAcc<MODEL> gacc;
+  gacc.zero();
+  lane_normal_fused<MODEL>(tv, I, p, acc, gacc);
+  if (WRITE_BLOCKS) {
+#pragma unroll
+    for (int e = 0; e < 21; ++e) Vb[e * S + slot] = acc.V[e];
+#pragma unroll
+    for (int e = 0; e < NI * 6; ++e) Wb[e * S + slot] = acc.W[e];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) gb[e * S + slot] = acc.g[e];
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const double s = wave_sum(gacc.v[i]);
+    if (lane == 0) scratch[(size_t)i * scratch_stride + tile] = s;
+  }
+  double sacc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
+  if (tv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double s = wave_sum(sacc[i]);
+    if (lane == 0) scratch[(size_t)(NG + i) * scratch_stride + tile] = s;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_finalize_strided(const double* __restrict__ scratch, int n_part, int stride,
+                                                          double* __restrict__ out) {
+  __shared__ double sh[TPB];
+  const int i = blockIdx.x;
+  double s = 0.0;
+  for (int w = threadIdx.x; w < n_part; w += TPB) s += scratch[(size_t)i * stride + w];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = TPB / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[i] = sh[0];
+}
+
 template <int MODEL>
 __global__ __launch_bounds__(TPB) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
                                                      double* __restrict__ pose, int max_iter, double tol,
@@ -312,9 +375,10 @@ int camcal_schur_len(int model) {
   const int ni = camcal_n_intr(model);
   return ni < 0 ? ni : ni * (ni + 1) / 2 + ni;
 }
-int64_t camcal_scratch_len(int model) {
+int64_t camcal_scratch_len(int model, int n_tiles) {
   (void)model;
-  return (int64_t)MAX_NV * MAX_WAVES;
+  const int64_t a = (int64_t)MAX_NV * MAX_WAVES, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
+  return a > b ? a : b;
 }
 
 int camcal_pack_tiles(const float* obj_xyz, const float* img_uv, const int64_t* view_ptr,
@@ -438,17 +502,40 @@ int camcal_backsub(int model, const camcal_tiles* tiles, const double* V, const 
 
 int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
                      double* V, double* W, double* g, double* glob, double* schur, double* scratch, void* stream) {
-  int rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
-  if (rc) return rc;
-  rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
-  if (rc) return rc;
-  return camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !schur || !scratch) return CAMCAL_E_BADARG;
+  const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
+  if (ng < 0) return ng;
+  const bool wb = V && W && g;
+  if (!wb && (V || W || g)) return CAMCAL_E_BADARG;
+  if (schur != glob + ng) {
+    // separate records: fall back to the staged form
+    int rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
+    if (rc) return rc;
+    if (!wb) return CAMCAL_E_BADARG;
+    rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
+    if (rc) return rc;
+    return camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
+  }
+  const dim3 gr(grid_tiles(tiles)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = tiles->n_tiles;
+  if (model == CAMCAL_PINHOLE) {
+    if (wb) hipLaunchKernelGGL((k_normal_fused<PINHOLE, true>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
+    else hipLaunchKernelGGL((k_normal_fused<PINHOLE, false>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
+  } else {
+    if (wb) hipLaunchKernelGGL((k_normal_fused<FISHEYE, true>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
+    else hipLaunchKernelGGL((k_normal_fused<FISHEYE, false>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
+  }
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize_strided, dim3(ng + ns), dim3(TPB), 0, s, scratch, nt, nt, glob);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles, const double* intr,
                       const double* pose, double lam, double* V, double* W, double* g, double* glob, double* schur,
                       double* scratch, void* stream, float* ms_out_host) {
-  if (reps <= 0 || !ms_out_host || stage < 0 || stage > 2) return CAMCAL_E_BADARG;
+  if (reps <= 0 || !ms_out_host || stage < 0 || stage > 3) return CAMCAL_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
@@ -458,7 +545,8 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
   for (int r = 0; r < reps && rc == 0; ++r) {
     if (stage == 0) rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
     else if (stage == 1) rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
-    else rc = camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
+    else if (stage == 2) rc = camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
+    else rc = camcal_normal_eq(model, tiles, intr, pose, lam, V, W, g, glob, schur, scratch, stream);
   }
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));
@@ -497,3 +585,4 @@ int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream
 }
 
 }  // extern "C"
+

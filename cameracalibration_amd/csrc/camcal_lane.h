@@ -49,6 +49,60 @@ CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double
 }
 
 // ---------------------------------------------------------------------------
+// K1+K2 fused: one pass over the view's corners feeding both accumulator sets
+// (projection and Jacobian evaluated once per observation).
+template <int MODEL>
+CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const double pose[6],
+                             ViewAcc<MODEL>& acc, IntrAcc<MODEL>& gacc) {
+  double R[9];
+  rodrigues(pose, R);
+  const double t[3] = {pose[3], pose[4], pose[5]};
+  acc.zero();
+  Obs cur = load_obs(tv.base, 0);
+  for (int k = 0; k < tv.nmax; ++k) {
+    const Obs nxt = load_obs(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
+    if (k < tv.n) {
+      double Yr[3], Yc[3];
+      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      PointEval<MODEL> p;
+      eval_point<true>(Yc, intr, p);
+      const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
+      accumulate_intr(gacc, p, eu, ev);
+      accumulate_view(acc, p, Yr, eu, ev);
+    }
+    cur = nxt;
+  }
+  double Jl[9];
+  left_jacobian(pose, Jl);
+  to_rodrigues_frame<MT<MODEL>::NI>(Jl, acc.V, acc.W, acc.g);
+}
+
+// Schur contribution of one view from blocks held in registers (consumes V, W, g).
+template <int NI>
+CC_HD void lane_schur_regs(double V[21], double* W, double g[6], double lam, double* acc) {
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) V[tri(6, i, i)] *= 1.0 + lam;
+  chol6(V);
+  chol6_fwd(V, g);
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) chol6_fwd(V, W + a * 6);
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) {
+    CC_UNROLL
+    for (int b = a; b < NI; ++b) {
+      double s = 0.0;
+      CC_UNROLL
+      for (int c = 0; c < 6; ++c) s = fma(W[a * 6 + c], W[b * 6 + c], s);
+      acc[tri(NI, a, b)] += s;
+    }
+    double s = 0.0;
+    CC_UNROLL
+    for (int c = 0; c < 6; ++c) s = fma(W[a * 6 + c], g[c], s);
+    acc[trisz(NI) + a] += s;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K2: intrinsic normal block U, b and the cost (global sums); also returns the
 // lane's own view cost (sum of squared residuals).  NORMAL=false: cost only.
 template <int MODEL, bool NORMAL>
@@ -68,7 +122,8 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
       eval_point<NORMAL>(Yc, intr, p);
       const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
       if (NORMAL) accumulate_intr(acc, p, eu, ev);
-      vc += eu * eu + ev * ev;
+      vc = fma(eu, eu, vc);
+      vc = fma(ev, ev, vc);
     }
     cur = nxt;
   }
@@ -109,8 +164,12 @@ CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6
       CC_UNROLL
       for (int i = 0; i < 6; ++i) {
         CC_UNROLL
-        for (int j = i; j < 6; ++j) V[tri(6, i, j)] += ju[i] * ju[j] + jv[i] * jv[j];
-        g[i] += eu * ju[i] + ev * jv[i];
+        for (int j = i; j < 6; ++j) {
+          V[tri(6, i, j)] = fma(ju[i], ju[j], V[tri(6, i, j)]);
+          V[tri(6, i, j)] = fma(jv[i], jv[j], V[tri(6, i, j)]);
+        }
+        g[i] = fma(eu, ju[i], g[i]);
+        g[i] = fma(ev, jv[i], g[i]);
       }
       cur = nxt;
     }

@@ -63,6 +63,43 @@ CC_HD constexpr int tri(int n, int i, int j) { return i * n - (i * (i - 1)) / 2 
 CC_HD constexpr int trisz(int n) { return n * (n + 1) / 2; }
 
 // ---------------------------------------------------------------------------
+// Reciprocal and reciprocal square root for the per-observation path.  On the
+// device: the hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-26) plus two Newton
+// steps, i.e. full double accuracy (<= 1-2 ulp) in 5-7 instructions instead of
+// the ~12/~22 of the IEEE division / sqrt expansions.  Arguments here are
+// finite, normal and positive (depths, radii), so the special-case handling of
+// the IEEE expansions is not needed.  The CPU emulator uses the plain forms.
+CC_HD double fast_rcp(double a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(a);
+  double e = fma(-a, y, 1.0);
+  y = fma(y, e, y);
+  e = fma(-a, y, 1.0);
+  return fma(y, e, y);
+#else
+  return 1.0 / a;
+#endif
+}
+// returns 1/sqrt(a) and sqrt(a) (through rt); a > 0
+CC_HD double fast_rsqrt(double a, double& rt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(a);
+  const double h = 0.5 * a;
+  double e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  e = fma(-h * y, y, 0.5);
+  y = fma(y, e, y);
+  double r = a * y;
+  r = fma(fma(-r, r, a), 0.5 * y, r);
+  rt = r;
+  return y;
+#else
+  rt = sqrt(a);
+  return 1.0 / rt;
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // Rodrigues vector -> rotation matrix (row-major), as cvRodrigues2.
 CC_HD void rodrigues(const double r[3], double R[9]) {
   const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -115,7 +152,7 @@ template <bool JAC>
 CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<PINHOLE>& o) {
   const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
   const double k1 = intr[4], k2 = intr[5], p1 = intr[6], p2 = intr[7], k3 = intr[8];
-  const double z = Yc[2] != 0.0 ? 1.0 / Yc[2] : 1.0;
+  const double z = Yc[2] != 0.0 ? fast_rcp(Yc[2]) : 1.0;
   const double x = Yc[0] * z, y = Yc[1] * z;
   const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
   const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
@@ -148,12 +185,14 @@ template <bool JAC>
 CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>& o) {
   const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
   const double k1 = intr[4], k2 = intr[5], k3 = intr[6], k4 = intr[7];
-  const double iz = 1.0 / Yc[2];
+  const double iz = fast_rcp(Yc[2]);
   const double x = Yc[0] * iz, y = Yc[1] * iz;
   const double r2 = x * x + y * y;
-  const double rr = sqrt(r2);
-  const bool big = rr > 1e-8;
-  const double inv_r = big ? 1.0 / rr : 1.0;
+  const bool big = r2 > 1e-16;                   // cv2: r > 1e-8
+  double rr;
+  double inv_r = fast_rsqrt(big ? r2 : 1.0, rr);
+  rr = big ? rr : sqrt(r2);
+  inv_r = big ? inv_r : 1.0;
   const double th = atan(rr);
   const double th2 = th * th;
   const double poly = 1.0 + th2 * (k1 + th2 * (k2 + th2 * (k3 + th2 * k4)));
@@ -172,7 +211,7 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
     o.au[5] = fxx * tp; o.av[5] = fyy * tp;
     const double dpoly = 1.0 + th2 * (3.0 * k1 + th2 * (5.0 * k2 + th2 * (7.0 * k3 + th2 * 9.0 * k4)));
     // s(r) = theta_d / r ;  q = (ds/dr)/r
-    const double q = big ? (dpoly / (1.0 + r2) - cdist) * inv_r * inv_r : 0.0;
+    const double q = big ? (dpoly * fast_rcp(1.0 + r2) - cdist) * inv_r * inv_r : 0.0;
     const double a = cdist + x * x * q, b = x * y * q, c = cdist + y * y * q;
     const double fxz = fx * iz, fyz = fy * iz;
     o.gu[0] = fxz * a; o.gu[1] = fxz * b; o.gu[2] = -fxz * (x * a + y * b);
@@ -233,15 +272,19 @@ CC_HD void accumulate_view(ViewAcc<MODEL>& A, const PointEval<MODEL>& p, const d
 CC_UNROLL
   for (int i = 0; i < 6; ++i) {
 CC_UNROLL
-    for (int j = i; j < 6; ++j) A.V[tri(6, i, j)] += ju[i] * ju[j] + jv[i] * jv[j];
-    A.g[i] += eu * ju[i] + ev * jv[i];
+    for (int j = i; j < 6; ++j) {
+      A.V[tri(6, i, j)] = fma(ju[i], ju[j], A.V[tri(6, i, j)]);
+      A.V[tri(6, i, j)] = fma(jv[i], jv[j], A.V[tri(6, i, j)]);
+    }
+    A.g[i] = fma(eu, ju[i], A.g[i]);
+    A.g[i] = fma(ev, jv[i], A.g[i]);
   }
 CC_UNROLL
   for (int a = 0; a < T::NA; ++a) {
 CC_UNROLL
     for (int c = 0; c < 6; ++c) {
-      A.W[T::ucol(a) * 6 + c] += p.au[a] * ju[c];
-      A.W[T::vcol(a) * 6 + c] += p.av[a] * jv[c];
+      A.W[T::ucol(a) * 6 + c] = fma(p.au[a], ju[c], A.W[T::ucol(a) * 6 + c]);
+      A.W[T::vcol(a) * 6 + c] = fma(p.av[a], jv[c], A.W[T::vcol(a) * 6 + c]);
     }
   }
 }
@@ -255,13 +298,14 @@ CC_UNROLL
   for (int a = 0; a < T::NA; ++a) {
 CC_UNROLL
     for (int b = a; b < T::NA; ++b) {
-      A.v[tri(NI, T::ucol(a), T::ucol(b))] += p.au[a] * p.au[b];
-      A.v[tri(NI, T::vcol(a), T::vcol(b))] += p.av[a] * p.av[b];
+      A.v[tri(NI, T::ucol(a), T::ucol(b))] = fma(p.au[a], p.au[b], A.v[tri(NI, T::ucol(a), T::ucol(b))]);
+      A.v[tri(NI, T::vcol(a), T::vcol(b))] = fma(p.av[a], p.av[b], A.v[tri(NI, T::vcol(a), T::vcol(b))]);
     }
-    A.v[NU + T::ucol(a)] += p.au[a] * eu;
-    A.v[NU + T::vcol(a)] += p.av[a] * ev;
+    A.v[NU + T::ucol(a)] = fma(p.au[a], eu, A.v[NU + T::ucol(a)]);
+    A.v[NU + T::vcol(a)] = fma(p.av[a], ev, A.v[NU + T::vcol(a)]);
   }
-  A.v[NU + NI] += eu * eu + ev * ev;
+  A.v[NU + NI] = fma(eu, eu, A.v[NU + NI]);
+  A.v[NU + NI] = fma(ev, ev, A.v[NU + NI]);
 }
 
 // Map the local-frame blocks of one view to Rodrigues coordinates (in place):

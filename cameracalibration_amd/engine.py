@@ -110,7 +110,7 @@ class Engine:
         self.stats = torch.zeros(8, **f64)
         self.norms = torch.zeros(2, **f64)
         self.view_cost = torch.zeros(S, **f64)
-        self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model)), **f64)
+        self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model, lay["n_tiles"])), **f64)
         self.status = torch.zeros(S, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(S, dtype=torch.int32, device=dev)
 
@@ -210,11 +210,14 @@ class Engine:
                    self.pose[pose_out].data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(),
                    self._stream())
 
-    def normal_eq(self, intr_idx, pose_idx, glob_idx, lam):
-        """One full normal-equation evaluation (the benchmarked unit)."""
+    def normal_eq(self, intr_idx, pose_idx, lam, store_blocks=True):
+        """One full normal-equation evaluation (the benchmarked unit) into
+        ``self.rec`` = [U|b|cost|C|d]; fused single pass over the points."""
+        sb = bool(store_blocks)
         self._call("camcal_normal_eq", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
-                   self.pose[pose_idx].data_ptr(), float(lam), self.V.data_ptr(), self.W.data_ptr(),
-                   self.g.data_ptr(), self.glob[glob_idx].data_ptr(), self.schur.data_ptr(),
+                   self.pose[pose_idx].data_ptr(), float(lam),
+                   self.V.data_ptr() if sb else None, self.W.data_ptr() if sb else None,
+                   self.g.data_ptr() if sb else None, self.glob[0].data_ptr(), self.schur.data_ptr(),
                    self.scratch.data_ptr(), self._stream())
 
     def time_stage(self, stage, reps, lam=0.0):

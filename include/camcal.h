@@ -64,8 +64,8 @@ int camcal_glob_len(int model);
 int camcal_schur_len(int model);
 
 /* Doubles of scratch the reducing entry points need (partial sums of the
- * launched wavefronts); depends only on the model. */
-int64_t camcal_scratch_len(int model);
+ * launched wavefronts) for a problem of n_tiles tiles. */
+int64_t camcal_scratch_len(int model, int n_tiles);
 
 /* Gather cv2-style AoS points into tiles.  obj_xyz [n_obs][3] f32, img_uv
  * [n_obs][2] f32, view_ptr [n_views+1] i64 (CSR), slot_view [n_slots] i32 =
@@ -129,15 +129,19 @@ int camcal_backsub(int model, const camcal_tiles* tiles, const double* V, const 
                    const double* g, double lam, const double* dK, const double* pose_in,
                    double* pose_out, double* norms, double* scratch, void* stream);
 
-/* One full normal-equation evaluation = camcal_intr_normal(with_normal=1) +
- * camcal_view_blocks + camcal_schur, the unit the benchmark times. */
+/* One full normal-equation evaluation (the unit the benchmark times): same
+ * results as camcal_intr_normal(with_normal=1) + camcal_view_blocks +
+ * camcal_schur.  When `schur == glob + camcal_glob_len(model)` (one contiguous
+ * record) it runs as ONE fused pass over the points; V, W, g may then all be
+ * NULL to skip storing the per-view blocks (Gauss-Newton callers that never
+ * back-substitute). */
 int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr,
                      const double* pose, double lam, double* V, double* W, double* g,
                      double* glob, double* schur, double* scratch, void* stream);
 
 /* Timing helper for benchmarks: average duration in milliseconds of `reps`
  * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,
- * 2 = schur), measured with HIP events on `stream`. */
+ * 2 = schur, 3 = the fused camcal_normal_eq), measured with HIP events on `stream`. */
 int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
                       const double* intr, const double* pose, double lam, double* V, double* W,
                       double* g, double* glob, double* schur, double* scratch, void* stream,

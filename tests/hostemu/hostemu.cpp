@@ -131,7 +131,7 @@ int camcal_version(void) { return -100; }   // negative: emulator
 int camcal_n_intr(int model) { return model == 0 ? 9 : model == 1 ? 8 : CAMCAL_E_BADMODEL; }
 int camcal_glob_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni + 1; }
 int camcal_schur_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni; }
-int64_t camcal_scratch_len(int) { return 64; }
+int64_t camcal_scratch_len(int, int) { return 64; }
 
 int camcal_pack_tiles(const float* obj, const float* img, const int64_t* view_ptr, const int32_t* slot_view,
                       const camcal_tiles* t, float* out, void*) {
@@ -187,6 +187,11 @@ int camcal_backsub(int model, const camcal_tiles* t, const double* V, const doub
 int camcal_normal_eq(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam, double* V,
                      double* W, double* g, double* glob, double* schur_out, double* scratch, void* s) {
   camcal_intr_normal(model, t, intr, pose, 1, glob, nullptr, scratch, s);
+  std::vector<double> tV, tW, tg;
+  if (!V) {
+    tV.resize(21 * t->n_slots); tW.resize(54 * t->n_slots); tg.resize(6 * t->n_slots);
+    V = tV.data(); W = tW.data(); g = tg.data();
+  }
   camcal_view_blocks(model, t, intr, pose, V, W, g, s);
   return camcal_schur(model, t, V, W, g, lam, schur_out, scratch, s);
 }

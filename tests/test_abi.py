@@ -35,7 +35,7 @@ def test_query_entry_points_need_no_gpu():
     assert lib.camcal_n_intr(0) == 9 and lib.camcal_n_intr(1) == 8 and lib.camcal_n_intr(7) < 0
     assert lib.camcal_glob_len(0) == 55 and lib.camcal_glob_len(1) == 45
     assert lib.camcal_schur_len(0) == 54 and lib.camcal_schur_len(1) == 44
-    assert lib.camcal_scratch_len(1) >= 64 * 64
+    assert lib.camcal_scratch_len(1, 100) >= 64 * 64 and lib.camcal_scratch_len(1, 20000) >= 89 * 20000
 
 
 def test_emulator_exports_the_same_abi(emu):

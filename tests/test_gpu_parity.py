@@ -53,7 +53,7 @@ def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv):
     E.set_intr(0, g)
     E.set_poses(0, poses)
     lam = 1e-3
-    E.normal_eq(0, 0, 0, lam)
+    E.normal_eq(0, 0, lam)
     blk = O.normal_blocks(model, views, g, poses)
     NI, nu = E.NI, E.NI * (E.NI + 1) // 2
     G = E.glob[0].cpu().numpy()
@@ -199,7 +199,7 @@ def test_full_size_properties_config3_and_5(dev):
         P = synth.config(name, n_views=nv, device=dev)
         E = _engine_for(P, dev)
         E.set_intr(0, P.intr_true())
-        E.normal_eq(0, 0, 0, 0.0)
+        E.normal_eq(0, 0, 0.0)
         full = E.rec.cpu().numpy().copy()
         sigma2 = full[E.glob_len - 1] / (2 * P.n_obs)
         assert abs(sigma2 - 0.04) < 0.04 * 0.01 + 1e-5            # noise 0.2 px (+ float32 rounding)
@@ -212,7 +212,7 @@ def test_full_size_properties_config3_and_5(dev):
                               P.poses_true[lo:hi])
             Eh = _engine_for(Q, dev)
             Eh.set_intr(0, P.intr_true())
-            Eh.normal_eq(0, 0, 0, 0.0)
+            Eh.normal_eq(0, 0, 0.0)
             parts.append(Eh.rec.cpu().numpy().copy())
             del Eh, Q
         assert np.allclose(parts[0] + parts[1], full, rtol=1e-9, atol=1e-6 * np.abs(full).max())
@@ -225,7 +225,7 @@ def test_full_size_properties_config3_and_5(dev):
                           P.obj[:vp[ns]], P.img[:vp[ns]], P.poses_true[:ns])
         Es = _engine_for(Q, dev)
         Es.set_intr(0, P.intr_true())
-        Es.normal_eq(0, 0, 0, 0.0)
+        Es.normal_eq(0, 0, 0.0)
         G = Es.rec.cpu().numpy()
         nu = 36
         assert rel(sym(G[:nu], 8), r["U"]) < 1e-11 and rel(G[nu:nu + 8], r["b"]) < 1e-9
