@@ -19,7 +19,8 @@ PINHOLE, FISHEYE = 0, 1
 class Tiles(C.Structure):
     """struct camcal_tiles (include/camcal.h)."""
     _fields_ = [("pts", C.c_void_p), ("tile_off", C.c_void_p), ("tile_nmax", C.c_void_p),
-                ("lane_n", C.c_void_p), ("n_tiles", C.c_int32), ("n_slots", C.c_int64)]
+                ("lane_n", C.c_void_p), ("n_tiles", C.c_int32), ("n_slots", C.c_int64),
+                ("planar", C.c_int32)]
 
 
 _P, _I, _D = C.c_void_p, C.c_int, C.c_double

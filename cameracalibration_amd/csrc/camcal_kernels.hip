@@ -24,6 +24,12 @@ constexpr int WPB = TPB / LANES;
 constexpr int MAX_WAVES = 4096;          // persistent waves of a reducing kernel (16 per CU)
 constexpr int MAX_NV = 64;               // widest reduced record (pinhole: 45 + 9 + 1 = 55)
 
+#define DISPATCH_MODEL_PLANAR(model, planar, L)                       \
+  do {                                                                \
+    if ((model) == CAMCAL_PINHOLE) { if (planar) L(PINHOLE, true); else L(PINHOLE, false); } \
+    else { if (planar) L(FISHEYE, true); else L(FISHEYE, false); }   \
+  } while (0)
+
 #define HIP_TRY(x)                                  \
   do {                                              \
     hipError_t e_ = (x);                            \
@@ -83,7 +89,7 @@ __device__ __forceinline__ void load_intr(const double* __restrict__ intr, doubl
 }
 
 // ---------------------------------------------------------------------------
-template <int MODEL>
+template <int MODEL, bool PLANAR>
 __global__ __launch_bounds__(TPB) void k_view_blocks(camcal_tiles t, const double* __restrict__ intr,
                                                      const double* __restrict__ pose,
                                                      double* __restrict__ Vb, double* __restrict__ Wb,
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(TPB) void k_view_blocks(camcal_tiles t, const doubl
   load_pose(pose, S, slot, p);
   const LaneTile tv = lane_tile(t, tile, lane);
   ViewAcc<MODEL> acc;
-  lane_view_blocks<MODEL>(tv, I, p, acc);
+  lane_view_blocks<MODEL, PLANAR>(tv, I, p, acc);
 #pragma unroll
   for (int e = 0; e < 21; ++e) Vb[e * S + slot] = acc.V[e];
 #pragma unroll
@@ -107,13 +113,14 @@ __global__ __launch_bounds__(TPB) void k_view_blocks(camcal_tiles t, const doubl
   for (int e = 0; e < 6; ++e) gb[e * S + slot] = acc.g[e];
 }
 
-template <int MODEL, bool NORMAL>
+template <int MODEL, bool NORMAL, bool PLANAR>
 __global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const double* __restrict__ intr,
                                                      const double* __restrict__ pose,
                                                      double* __restrict__ view_cost,
                                                      double* __restrict__ scratch) {
   constexpr int NI = MT<MODEL>::NI;
-  constexpr int NV = IntrAcc<MODEL>::NV;
+  constexpr int NR = IntrAcc<MODEL>::NR;
+  constexpr int COST = IntrAcc<MODEL>::COST;
   const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * WPB;
   const int lane = threadIdx.x & 63;
@@ -127,28 +134,28 @@ __global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const doubl
     double p[6];
     load_pose(pose, S, slot, p);
     const LaneTile tv = lane_tile(t, tile, lane);
-    const double vc = lane_intr_normal<MODEL, NORMAL>(tv, I, p, acc);
+    const double vc = lane_intr_normal<MODEL, NORMAL, PLANAR>(tv, I, p, acc);
     if (view_cost) view_cost[slot] = vc;
   }
   if (NORMAL) {
-    wave_reduce_store<NV>(acc.v, scratch, wave);
+    wave_reduce_store<NR>(acc.v, scratch, wave);
   } else {
-    const double s = wave_sum(acc.v[NV - 1]);
-    if (lane == 0) scratch[(size_t)(NV - 1) * MAX_WAVES + wave] = s;
+    const double s = wave_sum(acc.v[COST]);
+    if (lane == 0) scratch[(size_t)COST * MAX_WAVES + wave] = s;
   }
 }
 
 // Fused normal-equation evaluation: U, b, cost + per-view blocks + Schur
 // complement in one pass over the points.  One tile per wavefront; the wave's
 // partial record [U|b|cost|C|d] goes to scratch[i][tile] (second stage sums).
-template <int MODEL, bool WRITE_BLOCKS>
+template <int MODEL, bool WRITE_BLOCKS, bool PLANAR>
 __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const double* __restrict__ intr,
                                                       const double* __restrict__ pose, double lam,
                                                       double* __restrict__ Vb, double* __restrict__ Wb,
                                                       double* __restrict__ gb, double* __restrict__ scratch,
                                                       int scratch_stride) {
   constexpr int NI = MT<MODEL>::NI;
-  constexpr int NG = IntrAcc<MODEL>::NV;
+  constexpr int NG = IntrAcc<MODEL>::NR;
   constexpr int NS = trisz(NI) + NI;
   const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
   if (tile >= t.n_tiles) return;
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   ViewAcc<MODEL> acc;
   IntrAcc<MODEL> gacc;
   gacc.zero();
-  lane_normal_fused<MODEL>(tv, I, p, acc, gacc);
+  lane_normal_fused<MODEL, PLANAR>(tv, I, p, acc, gacc);
   if (WRITE_BLOCKS) {
 #pragma unroll
     for (int e = 0; e < 21; ++e) Vb[e * S + slot] = acc.V[e];
@@ -201,7 +208,20 @@ __global__ __launch_bounds__(TPB) void k_finalize_strided(const double* __restri
   if (threadIdx.x == 0) out[i] = sh[0];
 }
 
+// reduced accumulator values -> record [U | b | cost] (+ n_tail values copied after it)
 template <int MODEL>
+__global__ void k_expand(const double* __restrict__ red, double* __restrict__ out, int n_tail, int cost_only) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  constexpr int NR = IntrAcc<MODEL>::NR, NV = IntrAcc<MODEL>::NV;
+  if (cost_only) { out[NV - 1] = red[IntrAcc<MODEL>::COST]; return; }
+  double r[NR], o[NV];
+  for (int i = 0; i < NR; ++i) r[i] = red[i];
+  IntrAcc<MODEL>::expand(r, o);
+  for (int i = 0; i < NV; ++i) out[i] = o[i];
+  for (int i = 0; i < n_tail; ++i) out[NV + i] = red[NR + i];
+}
+
+template <int MODEL, bool PLANAR>
 __global__ __launch_bounds__(TPB) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
                                                      double* __restrict__ pose, int max_iter, double tol,
                                                      int32_t* __restrict__ iters) {
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(TPB) void k_pose_refine(camcal_tiles t, const doubl
   double I[NI], p[6];
   load_intr<NI>(intr, I);
   load_pose(pose, S, slot, p);
-  const int it = lane_pose_refine<MODEL>(tv, I, p, max_iter, tol);
+  const int it = lane_pose_refine<MODEL, PLANAR>(tv, I, p, max_iter, tol);
 #pragma unroll
   for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
   if (iters) iters[slot] = it;
@@ -378,7 +398,7 @@ int camcal_schur_len(int model) {
 int64_t camcal_scratch_len(int model, int n_tiles) {
   (void)model;
   const int64_t a = (int64_t)MAX_NV * MAX_WAVES, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
-  return a > b ? a : b;
+  return (a > b ? a : b) + 2 * MAX_NV;   // + the reduced values ahead of their expansion
 }
 
 int camcal_pack_tiles(const float* obj_xyz, const float* img_uv, const int64_t* view_ptr,
@@ -405,13 +425,12 @@ int camcal_pose_init(int model, const camcal_tiles* tiles, const double* intr, d
 int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr, double* pose, int max_iter,
                        double tol, int32_t* iters, void* stream) {
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || max_iter < 0) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const dim3 g(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
-  if (model == CAMCAL_PINHOLE)
-    hipLaunchKernelGGL(k_pose_refine<PINHOLE>, g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
-  else if (model == CAMCAL_FISHEYE)
-    hipLaunchKernelGGL(k_pose_refine<FISHEYE>, g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
-  else return CAMCAL_E_BADMODEL;
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_pose_refine<M, P>), g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters)
+  DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -424,20 +443,25 @@ int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
   const int gp = grid_persistent(tiles);
   const dim3 g(gp), b(TPB);
   hipStream_t s = (hipStream_t)stream;
-  if (model == CAMCAL_PINHOLE) {
-    if (with_normal) hipLaunchKernelGGL((k_intr_normal<PINHOLE, true>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
-    else hipLaunchKernelGGL((k_intr_normal<PINHOLE, false>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
+  double* red = scratch + (size_t)MAX_NV * MAX_WAVES;      // reduced values ahead of their expansion
+  const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
+  const int ci = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::COST : IntrAcc<FISHEYE>::COST;
+  if (with_normal) {
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_intr_normal<M, true, P>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize, dim3(nr), dim3(TPB), 0, s, scratch, gp * WPB, red);
   } else {
-    if (with_normal) hipLaunchKernelGGL((k_intr_normal<FISHEYE, true>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
-    else hipLaunchKernelGGL((k_intr_normal<FISHEYE, false>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch);
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_intr_normal<M, false, P>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)ci * MAX_WAVES, gp * WPB, red + ci);
   }
   HIP_TRY(hipGetLastError());
-  if (with_normal) {
-    hipLaunchKernelGGL(k_finalize, dim3(len), dim3(TPB), 0, s, scratch, gp * WPB, glob);
-  } else {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)(len - 1) * MAX_WAVES, gp * WPB,
-                       glob + (len - 1));
-  }
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, 0, with_normal ? 0 : 1);
+  else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, 0, with_normal ? 0 : 1);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -445,11 +469,12 @@ int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
 int camcal_view_blocks(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double* V,
                        double* W, double* g, void* stream) {
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !V || !W || !g) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const dim3 gr(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
-  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_view_blocks<PINHOLE>, gr, b, 0, s, *tiles, intr, pose, V, W, g);
-  else if (model == CAMCAL_FISHEYE) hipLaunchKernelGGL(k_view_blocks<FISHEYE>, gr, b, 0, s, *tiles, intr, pose, V, W, g);
-  else return CAMCAL_E_BADMODEL;
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_view_blocks<M, P>), gr, b, 0, s, *tiles, intr, pose, V, W, g)
+  DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -519,15 +544,22 @@ int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, c
   const dim3 gr(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   const int nt = tiles->n_tiles;
-  if (model == CAMCAL_PINHOLE) {
-    if (wb) hipLaunchKernelGGL((k_normal_fused<PINHOLE, true>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
-    else hipLaunchKernelGGL((k_normal_fused<PINHOLE, false>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
+  const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
+  double* red = scratch + (size_t)(nr + ns) * nt;
+  if (wb) {
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
   } else {
-    if (wb) hipLaunchKernelGGL((k_normal_fused<FISHEYE, true>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
-    else hipLaunchKernelGGL((k_normal_fused<FISHEYE, false>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt);
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, false, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
   }
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_finalize_strided, dim3(ng + ns), dim3(TPB), 0, s, scratch, nt, nt, glob);
+  hipLaunchKernelGGL(k_finalize_strided, dim3(nr + ns), dim3(TPB), 0, s, scratch, nt, nt, red);
+  HIP_TRY(hipGetLastError());
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);
+  else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -15,28 +15,30 @@ struct LaneTile {
 
 struct Obs { float X, Y, Z, u, v; };
 
+// PLANAR: every board point has Z == 0; the Z rows are never fetched.
+template <bool PLANAR>
 CC_HD Obs load_obs(const float* base, int k) {
   const float* p = base + (long long)k * (PT_COMP * LANES);
   Obs o;
-  o.X = p[0 * LANES]; o.Y = p[1 * LANES]; o.Z = p[2 * LANES]; o.u = p[3 * LANES]; o.v = p[4 * LANES];
+  o.X = p[0 * LANES]; o.Y = p[1 * LANES]; o.Z = PLANAR ? 0.f : p[2 * LANES]; o.u = p[3 * LANES]; o.v = p[4 * LANES];
   return o;
 }
 
 // ---------------------------------------------------------------------------
 // K1: per-view blocks V, W, g of the normal equations (Rodrigues frame).
-template <int MODEL>
+template <int MODEL, bool PLANAR>
 CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double pose[6],
                             ViewAcc<MODEL>& acc) {
   double R[9];
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   acc.zero();
-  Obs cur = load_obs(tv.base, 0);
+  Obs cur = load_obs<PLANAR>(tv.base, 0);
   for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);   // software prefetch
+    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);   // software prefetch
     if (k < tv.n) {
       double Yr[3], Yc[3];
-      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
       PointEval<MODEL> p;
       eval_point<true>(Yc, intr, p);
       accumulate_view(acc, p, Yr, p.pu - (double)cur.u, p.pv - (double)cur.v);
@@ -51,19 +53,19 @@ CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double
 // ---------------------------------------------------------------------------
 // K1+K2 fused: one pass over the view's corners feeding both accumulator sets
 // (projection and Jacobian evaluated once per observation).
-template <int MODEL>
+template <int MODEL, bool PLANAR>
 CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const double pose[6],
                              ViewAcc<MODEL>& acc, IntrAcc<MODEL>& gacc) {
   double R[9];
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   acc.zero();
-  Obs cur = load_obs(tv.base, 0);
+  Obs cur = load_obs<PLANAR>(tv.base, 0);
   for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
+    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
     if (k < tv.n) {
       double Yr[3], Yc[3];
-      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
       PointEval<MODEL> p;
       eval_point<true>(Yc, intr, p);
       const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
@@ -72,6 +74,7 @@ CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const doubl
     }
     cur = nxt;
   }
+  gacc.add_count(tv.n);
   double Jl[9];
   left_jacobian(pose, Jl);
   to_rodrigues_frame<MT<MODEL>::NI>(Jl, acc.V, acc.W, acc.g);
@@ -105,19 +108,19 @@ CC_HD void lane_schur_regs(double V[21], double* W, double g[6], double lam, dou
 // ---------------------------------------------------------------------------
 // K2: intrinsic normal block U, b and the cost (global sums); also returns the
 // lane's own view cost (sum of squared residuals).  NORMAL=false: cost only.
-template <int MODEL, bool NORMAL>
+template <int MODEL, bool NORMAL, bool PLANAR>
 CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const double pose[6],
                               IntrAcc<MODEL>& acc) {
   double R[9];
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   double vc = 0.0;
-  Obs cur = load_obs(tv.base, 0);
+  Obs cur = load_obs<PLANAR>(tv.base, 0);
   for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
+    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
     if (k < tv.n) {
       double Yr[3], Yc[3];
-      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
       PointEval<MODEL> p;
       eval_point<NORMAL>(Yc, intr, p);
       const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
@@ -127,7 +130,8 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
     }
     cur = nxt;
   }
-  if (!NORMAL) acc.v[IntrAcc<MODEL>::NV - 1] += vc;
+  if (NORMAL) acc.add_count(tv.n);
+  else acc.v[IntrAcc<MODEL>::COST] += vc;
   return vc;
 }
 
@@ -136,7 +140,7 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
 // restatement of cv::internal::ComputeExtrinsicRefine: x += -(J^T J)^-1 J^T e,
 // stop when ||d|| / ||x + d|| <= tol or after max_iter steps.  Returns the
 // number of steps taken.  (cv2's cond(J) > 1e6 early-out is not evaluated.)
-template <int MODEL>
+template <int MODEL, bool PLANAR>
 CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6], int max_iter,
                            double tol) {
   int it = 0;
@@ -150,11 +154,11 @@ CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6
     for (int i = 0; i < 21; ++i) V[i] = 0.0;
     CC_UNROLL
     for (int i = 0; i < 6; ++i) g[i] = 0.0;
-    Obs cur = load_obs(tv.base, 0);
+    Obs cur = load_obs<PLANAR>(tv.base, 0);
     for (int k = 0; k < tv.n; ++k) {
-      const Obs nxt = load_obs(tv.base, (k + 1 < tv.n) ? k + 1 : k);
+      const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.n) ? k + 1 : k);
       double Yr[3], Yc[3];
-      transform_point(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
       PointEval<MODEL> p;
       eval_point<true>(Yc, intr, p);
       const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
@@ -388,7 +392,7 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
   // pass 1: centroid / spread of the board points
   double sx = 0, sy = 0, sxx = 0, syy = 0;
   for (int k = 0; k < n; ++k) {
-    const Obs o = load_obs(tv.base, k);
+    const Obs o = load_obs<true>(tv.base, k);
     sx += o.X; sy += o.Y; sxx += (double)o.X * o.X; syy += (double)o.Y * o.Y;
   }
   const double inv_n = 1.0 / n;
@@ -402,7 +406,7 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
   CC_UNROLL
   for (int i = 0; i < 8; ++i) b[i] = 0.0;
   for (int k = 0; k < n; ++k) {
-    const Obs o = load_obs(tv.base, k);
+    const Obs o = load_obs<true>(tv.base, k);
     double x, y;
     undistort_px<MODEL>(o.u, o.v, intr, x, y);
     const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
@@ -427,7 +431,7 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
     CC_UNROLL
     for (int i = 0; i < 8; ++i) b[i] = 0.0;
     for (int k = 0; k < n; ++k) {
-      const Obs o = load_obs(tv.base, k);
+      const Obs o = load_obs<true>(tv.base, k);
       double x, y;
       undistort_px<MODEL>(o.u, o.v, intr, x, y);
       const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;

@@ -145,6 +145,7 @@ template <int MODEL> struct PointEval {
   double gu[3], gv[3];       // d pu / dY, d pv / dY   (Y = camera-frame point)
   double au[MT<MODEL>::NA];  // intrinsic columns of the u row (au[1] == 1: cx)
   double av[MT<MODEL>::NA];  // intrinsic columns of the v row (av[1] == 1: cy)
+  double th2;                // fisheye only: theta^2 (au[2+j] = au[2] * th2^j)
 };
 
 // pinhole, 5 coefficients: intr = fx fy cx cy k1 k2 p1 p2 k3
@@ -203,6 +204,7 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
   if (JAC) {
     o.au[0] = xd; o.au[1] = 1.0;
     o.av[0] = yd; o.av[1] = 1.0;
+    o.th2 = th2;
     double tp = th * th2 * inv_r;       // theta^3 / r
     const double fxx = fx * x, fyy = fy * y;
     o.au[2] = fxx * tp; o.av[2] = fyy * tp; tp *= th2;
@@ -219,13 +221,21 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
   }
 }
 
-// camera-frame point and its rotated part
+// camera-frame point and its rotated part (PLANAR: board points with Z == 0)
+template <bool PLANAR>
 CC_HD void transform_point(const double R[9], const double t[3], float X, float Y, float Z,
                            double Yr[3], double Yc[3]) {
-  const double Xd = X, Yd = Y, Zd = Z;
-  Yr[0] = R[0] * Xd + R[1] * Yd + R[2] * Zd;
-  Yr[1] = R[3] * Xd + R[4] * Yd + R[5] * Zd;
-  Yr[2] = R[6] * Xd + R[7] * Yd + R[8] * Zd;
+  const double Xd = X, Yd = Y;
+  if (PLANAR) {
+    Yr[0] = R[0] * Xd + R[1] * Yd;
+    Yr[1] = R[3] * Xd + R[4] * Yd;
+    Yr[2] = R[6] * Xd + R[7] * Yd;
+  } else {
+    const double Zd = Z;
+    Yr[0] = R[0] * Xd + R[1] * Yd + R[2] * Zd;
+    Yr[1] = R[3] * Xd + R[4] * Yd + R[5] * Zd;
+    Yr[2] = R[6] * Xd + R[7] * Yd + R[8] * Zd;
+  }
   Yc[0] = Yr[0] + t[0]; Yc[1] = Yr[1] + t[1]; Yc[2] = Yr[2] + t[2];
 }
 
@@ -254,12 +264,56 @@ template <int MODEL> struct ViewAcc {   // per-view blocks in the local pose fra
   }
 };
 
-template <int MODEL> struct IntrAcc {   // global intrinsic normal block
+// Global intrinsic normal block.  NV = length of the record [U | b | cost];
+// NR = number of values a lane actually accumulates (and the wave reduces);
+// expand() maps the reduced values to the record.
+template <int MODEL> struct IntrAcc {
   static constexpr int NI = MT<MODEL>::NI;
   static constexpr int NU = trisz(NI);
   static constexpr int NV = NU + NI + 1;   // U | b | cost
-  double v[NV];
-  CC_HD void zero() { for (int i = 0; i < NV; ++i) v[i] = 0.0; }
+  static constexpr int NR = NV;
+  static constexpr int COST = NV - 1;      // index of the cost inside v[]
+  double v[NR];
+  CC_HD void zero() { for (int i = 0; i < NR; ++i) v[i] = 0.0; }
+  CC_HD void add_count(int) {}
+  CC_HD static void expand(const double* r, double* out) {
+    for (int i = 0; i < NV; ++i) out[i] = r[i];
+  }
+};
+
+// Kannala-Brandt: the intrinsic rows are (xd, 1, m t^0..t^3) and (yd, 1, n t^0..t^3)
+// with t = theta^2, so U has Hankel structure in the k block and needs only 27
+// distinct sums (not 36); fx/fy and cx/cy never mix.
+//   v[0..6]   H_p  = sum (m^2 + n^2) t^p          -> U(k_i, k_j) = H_{i+j}
+//   v[7..10]  sum xd^2, sum xd, sum yd^2, sum yd  -> U(fx,fx) U(fx,cx) U(fy,fy) U(fy,cy)
+//   v[11..14] sum xd m t^j  -> U(fx,k_j)    v[15..18] sum m t^j -> U(cx,k_j)
+//   v[19..22] sum yd n t^j  -> U(fy,k_j)    v[23..26] sum n t^j -> U(cy,k_j)
+//   v[27]     number of observations        -> U(cx,cx) = U(cy,cy)
+//   v[28..35] b (fx fy cx cy k1..k4), v[36] cost
+template <> struct IntrAcc<FISHEYE> {
+  static constexpr int NI = 8;
+  static constexpr int NU = 36;
+  static constexpr int NV = 45;
+  static constexpr int NR = 37;
+  static constexpr int COST = 36;
+  double v[NR];
+  CC_HD void zero() { for (int i = 0; i < NR; ++i) v[i] = 0.0; }
+  CC_HD void add_count(int n) { v[27] += (double)n; }
+  CC_HD static void expand(const double* r, double* out) {
+    for (int i = 0; i < NV; ++i) out[i] = 0.0;
+    out[tri(8, 0, 0)] = r[7];  out[tri(8, 0, 2)] = r[8];
+    out[tri(8, 1, 1)] = r[9];  out[tri(8, 1, 3)] = r[10];
+    out[tri(8, 2, 2)] = r[27]; out[tri(8, 3, 3)] = r[27];
+    for (int j = 0; j < 4; ++j) {
+      out[tri(8, 0, 4 + j)] = r[11 + j];
+      out[tri(8, 2, 4 + j)] = r[15 + j];
+      out[tri(8, 1, 4 + j)] = r[19 + j];
+      out[tri(8, 3, 4 + j)] = r[23 + j];
+      for (int i = 0; i <= j; ++i) out[tri(8, 4 + i, 4 + j)] = r[i + j];
+    }
+    for (int i = 0; i < 8; ++i) out[36 + i] = r[28 + i];
+    out[44] = r[36];
+  }
 };
 
 template <int MODEL>
@@ -306,6 +360,63 @@ CC_UNROLL
   }
   A.v[NU + NI] = fma(eu, eu, A.v[NU + NI]);
   A.v[NU + NI] = fma(ev, ev, A.v[NU + NI]);
+}
+// (pinhole counts cx/cy through its unit columns; add_count is a no-op there)
+
+// Fisheye specialisations: k rows share the 6-vector m6 = m ju + n jv, scaled by t^j.
+CC_HD void accumulate_view(ViewAcc<FISHEYE>& A, const PointEval<FISHEYE>& p, const double Yr[3],
+                           double eu, double ev) {
+  double ju[6], jv[6];
+  pose_row(Yr, p.gu, ju);
+  pose_row(Yr, p.gv, jv);
+  const double xd = p.au[0], yd = p.av[0], m = p.au[2], n = p.av[2], t1 = p.th2;
+  const double t2 = t1 * t1, t3 = t2 * t1;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) {
+      A.V[tri(6, i, j)] = fma(ju[i], ju[j], A.V[tri(6, i, j)]);
+      A.V[tri(6, i, j)] = fma(jv[i], jv[j], A.V[tri(6, i, j)]);
+    }
+    A.g[i] = fma(eu, ju[i], A.g[i]);
+    A.g[i] = fma(ev, jv[i], A.g[i]);
+    A.W[0 * 6 + i] = fma(xd, ju[i], A.W[0 * 6 + i]);
+    A.W[1 * 6 + i] = fma(yd, jv[i], A.W[1 * 6 + i]);
+    A.W[2 * 6 + i] += ju[i];
+    A.W[3 * 6 + i] += jv[i];
+    const double m6 = fma(m, ju[i], n * jv[i]);
+    A.W[4 * 6 + i] += m6;
+    A.W[5 * 6 + i] = fma(t1, m6, A.W[5 * 6 + i]);
+    A.W[6 * 6 + i] = fma(t2, m6, A.W[6 * 6 + i]);
+    A.W[7 * 6 + i] = fma(t3, m6, A.W[7 * 6 + i]);
+  }
+}
+
+CC_HD void accumulate_intr(IntrAcc<FISHEYE>& A, const PointEval<FISHEYE>& p, double eu, double ev) {
+  const double xd = p.au[0], yd = p.av[0], m = p.au[2], n = p.av[2], t1 = p.th2;
+  double tp[7];
+  tp[0] = 1.0; tp[1] = t1; tp[2] = t1 * t1; tp[3] = tp[2] * t1; tp[4] = tp[2] * tp[2]; tp[5] = tp[4] * t1;
+  tp[6] = tp[3] * tp[3];
+  const double w = fma(m, m, n * n);
+  A.v[0] += w;
+  CC_UNROLL
+  for (int q = 1; q < 7; ++q) A.v[q] = fma(w, tp[q], A.v[q]);
+  A.v[7] = fma(xd, xd, A.v[7]);  A.v[8] += xd;
+  A.v[9] = fma(yd, yd, A.v[9]);  A.v[10] += yd;
+  const double xm = xd * m, yn = yd * n, me = fma(m, eu, n * ev);
+  A.v[11] += xm; A.v[15] += m; A.v[19] += yn; A.v[23] += n; A.v[32] += me;
+  CC_UNROLL
+  for (int j = 1; j < 4; ++j) {
+    A.v[11 + j] = fma(xm, tp[j], A.v[11 + j]);
+    A.v[15 + j] = fma(m, tp[j], A.v[15 + j]);
+    A.v[19 + j] = fma(yn, tp[j], A.v[19 + j]);
+    A.v[23 + j] = fma(n, tp[j], A.v[23 + j]);
+    A.v[32 + j] = fma(me, tp[j], A.v[32 + j]);
+  }
+  A.v[28] = fma(xd, eu, A.v[28]); A.v[29] = fma(yd, ev, A.v[29]);
+  A.v[30] += eu; A.v[31] += ev;
+  A.v[36] = fma(eu, eu, A.v[36]);
+  A.v[36] = fma(ev, ev, A.v[36]);
 }
 
 // Map the local-frame blocks of one view to Rodrigues coordinates (in place):

@@ -82,9 +82,10 @@ class Engine:
         self.S = S
         self.tiles = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off.data_ptr(),
                                 self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
-                                lay["n_tiles"], S)
+                                lay["n_tiles"], S, 0)
         # pack on the device
         t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+        self.tiles.planar = 1 if bool((t_obj[:, 2] == 0).all().item()) else 0
         t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
         if t_obj.shape[0] != self.n_obs or t_img.shape[0] != self.n_obs:
             raise ValueError("view_ptr does not match the point arrays")

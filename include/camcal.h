@@ -51,6 +51,8 @@ typedef struct camcal_tiles {
   const int32_t* lane_n;     /* [n_slots] corners per slot, 0 = padding        */
   int32_t        n_tiles;
   int64_t        n_slots;    /* == 64 * n_tiles                                */
+  int32_t        planar;     /* 1: every object point has Z == 0 (the Z rows are
+                                then never read); 0: general 3-D points        */
 } camcal_tiles;
 
 /* Library version (major*10000 + minor*100 + patch). */

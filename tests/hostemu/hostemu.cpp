@@ -30,8 +30,8 @@ inline void load_pose(const double* pose, int64_t S, int64_t slot, double p[6]) 
 
 template <int MODEL, bool NORMAL>
 void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, double* glob, double* view_cost) {
-  constexpr int NV = IntrAcc<MODEL>::NV;
-  std::vector<double> tot(NV, 0.0);
+  constexpr int NV = IntrAcc<MODEL>::NV, NR = IntrAcc<MODEL>::NR;
+  std::vector<double> tot(NR, 0.0);
   for (int tile = 0; tile < t->n_tiles; ++tile) {
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -39,13 +39,14 @@ void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, 
       load_pose(pose, t->n_slots, slot, p);
       IntrAcc<MODEL> acc;
       acc.zero();
-      const double vc = lane_intr_normal<MODEL, NORMAL>(lane_tile(t, tile, lane), intr, p, acc);
+      const double vc = t->planar ? lane_intr_normal<MODEL, NORMAL, true>(lane_tile(t, tile, lane), intr, p, acc)
+                                  : lane_intr_normal<MODEL, NORMAL, false>(lane_tile(t, tile, lane), intr, p, acc);
       if (view_cost) view_cost[slot] = vc;
-      for (int i = 0; i < NV; ++i) tot[i] += acc.v[i];
+      for (int i = 0; i < NR; ++i) tot[i] += acc.v[i];
     }
   }
-  if (NORMAL) for (int i = 0; i < NV; ++i) glob[i] = tot[i];
-  else glob[NV - 1] = tot[NV - 1];
+  if (NORMAL) IntrAcc<MODEL>::expand(tot.data(), glob);
+  else glob[NV - 1] = tot[IntrAcc<MODEL>::COST];
 }
 
 template <int MODEL>
@@ -58,7 +59,8 @@ void view_blocks(const camcal_tiles* t, const double* intr, const double* pose, 
       double p[6];
       load_pose(pose, S, slot, p);
       ViewAcc<MODEL> acc;
-      lane_view_blocks<MODEL>(lane_tile(t, tile, lane), intr, p, acc);
+      if (t->planar) lane_view_blocks<MODEL, true>(lane_tile(t, tile, lane), intr, p, acc);
+      else lane_view_blocks<MODEL, false>(lane_tile(t, tile, lane), intr, p, acc);
       for (int e = 0; e < 21; ++e) V[e * S + slot] = acc.V[e];
       for (int e = 0; e < NI * 6; ++e) W[e * S + slot] = acc.W[e];
       for (int e = 0; e < 6; ++e) g[e * S + slot] = acc.g[e];
@@ -105,7 +107,8 @@ void pose_refine(const camcal_tiles* t, const double* intr, double* pose, int ma
       if (tv.n < 4) { if (iters) iters[slot] = 0; continue; }
       double p[6];
       load_pose(pose, S, slot, p);
-      const int it = lane_pose_refine<MODEL>(tv, intr, p, max_iter, tol);
+      const int it = t->planar ? lane_pose_refine<MODEL, true>(tv, intr, p, max_iter, tol)
+                               : lane_pose_refine<MODEL, false>(tv, intr, p, max_iter, tol);
       for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
       if (iters) iters[slot] = it;
     }
