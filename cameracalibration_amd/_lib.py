@@ -35,12 +35,14 @@ _SIGNATURES = {
     "camcal_pack_tiles": (C.c_int, [_P, _P, _P, _P, _TP, _P, _P]),
     "camcal_pose_init": (C.c_int, [_I, _TP, _P, _P, _P, _P]),
     "camcal_pose_refine": (C.c_int, [_I, _TP, _P, _P, _I, _D, _P, _P]),
-    "camcal_intr_normal": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P]),
+    "camcal_intr_normal": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "camcal_cross_schur": (C.c_int, [_I, _TP, _P, _P, _P, _P, _D, _P, _P, _P, _P]),
     "camcal_view_blocks": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P]),
     "camcal_schur": (C.c_int, [_I, _TP, _P, _P, _P, _D, _P, _P, _P]),
     "camcal_solve_reduced": (C.c_int, [_I, _P, _P, C.c_char_p, _D, _D, _P, _P, _P, _P, _P]),
     "camcal_backsub": (C.c_int, [_I, _TP, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
     "camcal_normal_eq": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
+    "camcal_normal_eq_fused": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_float)]),
     "camcal_peak_probe": (C.c_int, [_I, _P, C.c_int64, _I, _P, C.POINTER(C.c_double)]),

@@ -113,10 +113,12 @@ __global__ __launch_bounds__(TPB) void k_view_blocks(camcal_tiles t, const doubl
   for (int e = 0; e < 6; ++e) gb[e * S + slot] = acc.g[e];
 }
 
-template <int MODEL, bool NORMAL, bool PLANAR>
+// Evaluation A (persistent): cost / U, b / + per-view V, g (see lane_intr_normal).
+template <int MODEL, int MODE, bool PLANAR>
 __global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const double* __restrict__ intr,
                                                      const double* __restrict__ pose,
                                                      double* __restrict__ view_cost,
+                                                     double* __restrict__ Vb, double* __restrict__ gb,
                                                      double* __restrict__ scratch) {
   constexpr int NI = MT<MODEL>::NI;
   constexpr int NR = IntrAcc<MODEL>::NR;
@@ -134,14 +136,64 @@ __global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const doubl
     double p[6];
     load_pose(pose, S, slot, p);
     const LaneTile tv = lane_tile(t, tile, lane);
-    const double vc = lane_intr_normal<MODEL, NORMAL, PLANAR>(tv, I, p, acc);
+    double V[21], g[6];
+    const double vc = lane_intr_normal<MODEL, MODE, PLANAR>(tv, I, p, acc, V, g);
     if (view_cost) view_cost[slot] = vc;
+    if (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < 21; ++e) Vb[e * S + slot] = V[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) gb[e * S + slot] = g[e];
+    }
   }
-  if (NORMAL) {
+  if (MODE > 0) {
     wave_reduce_store<NR>(acc.v, scratch, wave);
   } else {
     const double s = wave_sum(acc.v[COST]);
     if (lane == 0) scratch[(size_t)COST * MAX_WAVES + wave] = s;
+  }
+}
+
+// Evaluation B: cross block W of every view + its Schur contribution
+// C += W V'^-1 W^T, d += W V'^-1 g with V, g read back from evaluation A.
+// One tile per wavefront; partial [C|d] of the tile -> scratch[i][tile].
+template <int MODEL, bool STORE_W, bool PLANAR>
+__global__ __launch_bounds__(TPB) void k_cross_schur(camcal_tiles t, const double* __restrict__ intr,
+                                                     const double* __restrict__ pose,
+                                                     const double* __restrict__ Vb, const double* __restrict__ gb,
+                                                     double lam, double* __restrict__ Wb,
+                                                     double* __restrict__ scratch, int scratch_stride) {
+  constexpr int NI = MT<MODEL>::NI;
+  constexpr int NS = trisz(NI) + NI;
+  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (tile >= t.n_tiles) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
+  double I[NI], p[6];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, slot, p);
+  const LaneTile tv = lane_tile(t, tile, lane);
+  double W[NI * 6];
+  lane_cross_block<MODEL, PLANAR>(tv, I, p, W);
+  if (STORE_W) {
+#pragma unroll
+    for (int e = 0; e < NI * 6; ++e) Wb[e * S + slot] = W[e];
+  }
+  double sacc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
+  if (tv.n > 0) {
+    double V[21], g[6];
+#pragma unroll
+    for (int e = 0; e < 21; ++e) V[e] = Vb[e * S + slot];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) g[e] = gb[e * S + slot];
+    lane_schur_regs<NI>(V, W, g, lam, sacc);
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double s = wave_sum(sacc[i]);
+    if (lane == 0) scratch[(size_t)i * scratch_stride + tile] = s;
   }
 }
 
@@ -436,32 +488,54 @@ int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr,
 }
 
 int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
-                       int with_normal, double* glob, double* view_cost, double* scratch, void* stream) {
+                       int with_normal, double* glob, double* view_cost, double* V, double* g, double* scratch,
+                       void* stream) {
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !scratch) return CAMCAL_E_BADARG;
+  if ((V == nullptr) != (g == nullptr) || (V && !with_normal)) return CAMCAL_E_BADARG;
   const int len = camcal_glob_len(model);
   if (len < 0) return len;
   const int gp = grid_persistent(tiles);
-  const dim3 g(gp), b(TPB);
+  const dim3 gr(gp), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   double* red = scratch + (size_t)MAX_NV * MAX_WAVES;      // reduced values ahead of their expansion
   const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
   const int ci = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::COST : IntrAcc<FISHEYE>::COST;
-  if (with_normal) {
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_intr_normal<M, true, P>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch)
-    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
-#undef LAUNCH
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize, dim3(nr), dim3(TPB), 0, s, scratch, gp * WPB, red);
-  } else {
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_intr_normal<M, false, P>), g, b, 0, s, *tiles, intr, pose, view_cost, scratch)
-    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
-#undef LAUNCH
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)ci * MAX_WAVES, gp * WPB, red + ci);
-  }
+#define LAUNCH2(M, P) hipLaunchKernelGGL((k_intr_normal<M, 2, P>), gr, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
+#define LAUNCH1(M, P) hipLaunchKernelGGL((k_intr_normal<M, 1, P>), gr, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
+#define LAUNCH0(M, P) hipLaunchKernelGGL((k_intr_normal<M, 0, P>), gr, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
+  if (with_normal && V) DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH2);
+  else if (with_normal) DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH1);
+  else DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH0);
+#undef LAUNCH0
+#undef LAUNCH1
+#undef LAUNCH2
+  HIP_TRY(hipGetLastError());
+  if (with_normal) hipLaunchKernelGGL(k_finalize, dim3(nr), dim3(TPB), 0, s, scratch, gp * WPB, red);
+  else hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)ci * MAX_WAVES, gp * WPB, red + ci);
   HIP_TRY(hipGetLastError());
   if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, 0, with_normal ? 0 : 1);
   else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, 0, with_normal ? 0 : 1);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_cross_schur(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
+                       const double* V, const double* g, double lam, double* W_out, double* schur,
+                       double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !V || !g || !schur || !scratch) return CAMCAL_E_BADARG;
+  const int ns = camcal_schur_len(model);
+  if (ns < 0) return ns;
+  const dim3 gr(grid_tiles(tiles)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = tiles->n_tiles;
+#define LAUNCHS(M, P) hipLaunchKernelGGL((k_cross_schur<M, true, P>), gr, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, nt)
+#define LAUNCHN(M, P) hipLaunchKernelGGL((k_cross_schur<M, false, P>), gr, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, nt)
+  if (W_out) DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCHS);
+  else DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCHN);
+#undef LAUNCHS
+#undef LAUNCHN
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize_strided, dim3(ns), dim3(TPB), 0, s, scratch, nt, nt, schur);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -527,20 +601,20 @@ int camcal_backsub(int model, const camcal_tiles* tiles, const double* V, const 
 
 int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
                      double* V, double* W, double* g, double* glob, double* schur, double* scratch, void* stream) {
+  if (!V || !g) return CAMCAL_E_BADARG;
+  int rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, V, g, scratch, stream);
+  if (rc) return rc;
+  return camcal_cross_schur(model, tiles, intr, pose, V, g, lam, W, schur, scratch, stream);
+}
+
+int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                     double* V, double* W, double* g, double* glob, double* schur, double* scratch, void* stream) {
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !schur || !scratch) return CAMCAL_E_BADARG;
   const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
   if (ng < 0) return ng;
   const bool wb = V && W && g;
   if (!wb && (V || W || g)) return CAMCAL_E_BADARG;
-  if (schur != glob + ng) {
-    // separate records: fall back to the staged form
-    int rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
-    if (rc) return rc;
-    if (!wb) return CAMCAL_E_BADARG;
-    rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
-    if (rc) return rc;
-    return camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
-  }
+  if (schur != glob + ng) return CAMCAL_E_BADARG;
   const dim3 gr(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   const int nt = tiles->n_tiles;
@@ -567,7 +641,7 @@ int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, c
 int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles, const double* intr,
                       const double* pose, double lam, double* V, double* W, double* g, double* glob, double* schur,
                       double* scratch, void* stream, float* ms_out_host) {
-  if (reps <= 0 || !ms_out_host || stage < 0 || stage > 3) return CAMCAL_E_BADARG;
+  if (reps <= 0 || !ms_out_host || stage < 0 || stage > 5) return CAMCAL_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
@@ -575,10 +649,12 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
   int rc = 0;
   HIP_TRY(hipEventRecord(e0, s));
   for (int r = 0; r < reps && rc == 0; ++r) {
-    if (stage == 0) rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, scratch, stream);
+    if (stage == 0) rc = camcal_intr_normal(model, tiles, intr, pose, 1, glob, nullptr, V, g, scratch, stream);
     else if (stage == 1) rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
     else if (stage == 2) rc = camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
-    else rc = camcal_normal_eq(model, tiles, intr, pose, lam, V, W, g, glob, schur, scratch, stream);
+    else if (stage == 3) rc = camcal_normal_eq(model, tiles, intr, pose, lam, V, W, g, glob, schur, scratch, stream);
+    else if (stage == 4) rc = camcal_normal_eq_fused(model, tiles, intr, pose, lam, V, W, g, glob, schur, scratch, stream);
+    else rc = camcal_cross_schur(model, tiles, intr, pose, V, g, lam, nullptr, schur, scratch, stream);
   }
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));

@@ -106,15 +106,23 @@ CC_HD void lane_schur_regs(double V[21], double* W, double g[6], double lam, dou
 }
 
 // ---------------------------------------------------------------------------
-// K2: intrinsic normal block U, b and the cost (global sums); also returns the
-// lane's own view cost (sum of squared residuals).  NORMAL=false: cost only.
-template <int MODEL, bool NORMAL, bool PLANAR>
+// Evaluation A: cost, intrinsic normal block U, b (global sums) and -- MODE 2
+// -- the view's pose block V and gradient g (Rodrigues frame, through V/g).
+// MODE 0: cost only; 1: U, b, cost; 2: U, b, cost, V, g.  Returns the lane's
+// own view cost (sum of squared residuals).
+template <int MODEL, int MODE, bool PLANAR>
 CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const double pose[6],
-                              IntrAcc<MODEL>& acc) {
+                              IntrAcc<MODEL>& acc, double* V, double* g) {
   double R[9];
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   double vc = 0.0;
+  if (MODE == 2) {
+    CC_UNROLL
+    for (int i = 0; i < 21; ++i) V[i] = 0.0;
+    CC_UNROLL
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  }
   Obs cur = load_obs<PLANAR>(tv.base, 0);
   for (int k = 0; k < tv.nmax; ++k) {
     const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
@@ -122,17 +130,57 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
       double Yr[3], Yc[3];
       transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
       PointEval<MODEL> p;
-      eval_point<NORMAL>(Yc, intr, p);
+      eval_point<(MODE > 0)>(Yc, intr, p);
       const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
-      if (NORMAL) accumulate_intr(acc, p, eu, ev);
+      if (MODE > 0) accumulate_intr(acc, p, eu, ev);
+      if (MODE == 2) {
+        double ju[6], jv[6];
+        pose_row(Yr, p.gu, ju);
+        pose_row(Yr, p.gv, jv);
+        accumulate_vg(V, g, ju, jv, eu, ev);
+      }
       vc = fma(eu, eu, vc);
       vc = fma(ev, ev, vc);
     }
     cur = nxt;
   }
-  if (NORMAL) acc.add_count(tv.n);
+  if (MODE > 0) acc.add_count(tv.n);
   else acc.v[IntrAcc<MODEL>::COST] += vc;
+  if (MODE == 2) {
+    double Jl[9];
+    left_jacobian(pose, Jl);
+    vg_to_rodrigues_frame(Jl, V, g);
+  }
   return vc;
+}
+
+// Evaluation B: the view's cross block W = Ji^T Je (Rodrigues frame).
+template <int MODEL, bool PLANAR>
+CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double pose[6], double* W) {
+  constexpr int NI = MT<MODEL>::NI;
+  double R[9];
+  rodrigues(pose, R);
+  const double t[3] = {pose[3], pose[4], pose[5]};
+  CC_UNROLL
+  for (int i = 0; i < NI * 6; ++i) W[i] = 0.0;
+  Obs cur = load_obs<PLANAR>(tv.base, 0);
+  for (int k = 0; k < tv.nmax; ++k) {
+    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
+    if (k < tv.n) {
+      double Yr[3], Yc[3];
+      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+      PointEval<MODEL> p;
+      eval_point<true>(Yc, intr, p);
+      double ju[6], jv[6];
+      pose_row(Yr, p.gu, ju);
+      pose_row(Yr, p.gv, jv);
+      accumulate_w(W, p, ju, jv);
+    }
+    cur = nxt;
+  }
+  double Jl[9];
+  left_jacobian(pose, Jl);
+  w_to_rodrigues_frame<NI>(Jl, W);
 }
 
 // ---------------------------------------------------------------------------
@@ -165,22 +213,12 @@ CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6
       double ju[6], jv[6];
       pose_row(Yr, p.gu, ju);
       pose_row(Yr, p.gv, jv);
-      CC_UNROLL
-      for (int i = 0; i < 6; ++i) {
-        CC_UNROLL
-        for (int j = i; j < 6; ++j) {
-          V[tri(6, i, j)] = fma(ju[i], ju[j], V[tri(6, i, j)]);
-          V[tri(6, i, j)] = fma(jv[i], jv[j], V[tri(6, i, j)]);
-        }
-        g[i] = fma(eu, ju[i], g[i]);
-        g[i] = fma(ev, jv[i], g[i]);
-      }
+      accumulate_vg(V, g, ju, jv, eu, ev);
       cur = nxt;
     }
     double Jl[9];
     left_jacobian(pose, Jl);
-    double Wdummy[6] = {0, 0, 0, 0, 0, 0};
-    to_rodrigues_frame<1>(Jl, V, Wdummy, g);
+    vg_to_rodrigues_frame(Jl, V, g);
     const bool ok = chol6(V);
     chol6_fwd(V, g);
     chol6_bwd(V, g);

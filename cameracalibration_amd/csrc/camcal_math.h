@@ -99,6 +99,31 @@ CC_HD double fast_rsqrt(double a, double& rt) {
 #endif
 }
 
+// atan(x) for x >= 0: reduction to |t| <= tan(pi/8) (t = x, (x-1)/(x+1) or -1/x)
+// and an 11-term odd polynomial (Chebyshev-node fit, max relative error
+// 5e-18 before rounding; coefficients from mpmath, tools/atan_coeffs.py).
+// Fewer constants than the 20-term libm form, which matters for registers.
+CC_HD double atan_pos(double x) {
+  const bool hi = x > 2.414213562373095, mid = x > 0.41421356237309503;
+  const double num = hi ? -1.0 : (mid ? x - 1.0 : x);
+  const double den = hi ? x : (mid ? x + 1.0 : 1.0);
+  const double base = hi ? 1.5707963267948966 : (mid ? 0.78539816339744831 : 0.0);
+  const double t = num * fast_rcp(den);
+  const double z = t * t;
+  double p = -0.019176887119062258989;
+  p = fma(p, z, 0.039231658295587191303);
+  p = fma(p, z, -0.050854497379402598613);
+  p = fma(p, z, 0.058581489128022098816);
+  p = fma(p, z, -0.066645114473819480001);
+  p = fma(p, z, 0.076921831908260865637);
+  p = fma(p, z, -0.090909045781239018905);
+  p = fma(p, z, 0.11111111015256361727);
+  p = fma(p, z, -0.14285714284666542922);
+  p = fma(p, z, 0.19999999999995520678);
+  p = fma(p, z, -0.3333333333333333016);
+  return base + fma(t * z, p, t);
+}
+
 // ---------------------------------------------------------------------------
 // Rodrigues vector -> rotation matrix (row-major), as cvRodrigues2.
 CC_HD void rodrigues(const double r[3], double R[9]) {
@@ -194,7 +219,7 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
   double inv_r = fast_rsqrt(big ? r2 : 1.0, rr);
   rr = big ? rr : sqrt(r2);
   inv_r = big ? inv_r : 1.0;
-  const double th = atan(rr);
+  const double th = atan_pos(rr);
   const double th2 = th * th;
   const double poly = 1.0 + th2 * (k1 + th2 * (k2 + th2 * (k3 + th2 * k4)));
   const double cdist = big ? th * poly * inv_r : 1.0;
@@ -316,31 +341,59 @@ template <> struct IntrAcc<FISHEYE> {
   }
 };
 
+// pose block V (6x6 upper) and gradient g from the two local-frame pose rows
+CC_HD void accumulate_vg(double V[21], double g[6], const double ju[6], const double jv[6], double eu, double ev) {
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) {
+      V[tri(6, i, j)] = fma(ju[i], ju[j], V[tri(6, i, j)]);
+      V[tri(6, i, j)] = fma(jv[i], jv[j], V[tri(6, i, j)]);
+    }
+    g[i] = fma(eu, ju[i], g[i]);
+    g[i] = fma(ev, jv[i], g[i]);
+  }
+}
+
+// intrinsic x pose cross block W (NI x 6)
+template <int MODEL>
+CC_HD void accumulate_w(double* W, const PointEval<MODEL>& p, const double ju[6], const double jv[6]) {
+  using T = MT<MODEL>;
+  CC_UNROLL
+  for (int a = 0; a < T::NA; ++a) {
+    CC_UNROLL
+    for (int c = 0; c < 6; ++c) {
+      W[T::ucol(a) * 6 + c] = fma(p.au[a], ju[c], W[T::ucol(a) * 6 + c]);
+      W[T::vcol(a) * 6 + c] = fma(p.av[a], jv[c], W[T::vcol(a) * 6 + c]);
+    }
+  }
+}
+// Kannala-Brandt: the k rows share the 6-vector m6 = m ju + n jv, scaled by t^j
+CC_HD void accumulate_w(double* W, const PointEval<FISHEYE>& p, const double ju[6], const double jv[6]) {
+  const double xd = p.au[0], yd = p.av[0], m = p.au[2], n = p.av[2], t1 = p.th2;
+  const double t2 = t1 * t1, t3 = t2 * t1;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    W[0 * 6 + i] = fma(xd, ju[i], W[0 * 6 + i]);
+    W[1 * 6 + i] = fma(yd, jv[i], W[1 * 6 + i]);
+    W[2 * 6 + i] += ju[i];
+    W[3 * 6 + i] += jv[i];
+    const double m6 = fma(m, ju[i], n * jv[i]);
+    W[4 * 6 + i] += m6;
+    W[5 * 6 + i] = fma(t1, m6, W[5 * 6 + i]);
+    W[6 * 6 + i] = fma(t2, m6, W[6 * 6 + i]);
+    W[7 * 6 + i] = fma(t3, m6, W[7 * 6 + i]);
+  }
+}
+
 template <int MODEL>
 CC_HD void accumulate_view(ViewAcc<MODEL>& A, const PointEval<MODEL>& p, const double Yr[3],
                            double eu, double ev) {
-  using T = MT<MODEL>;
   double ju[6], jv[6];
   pose_row(Yr, p.gu, ju);
   pose_row(Yr, p.gv, jv);
-CC_UNROLL
-  for (int i = 0; i < 6; ++i) {
-CC_UNROLL
-    for (int j = i; j < 6; ++j) {
-      A.V[tri(6, i, j)] = fma(ju[i], ju[j], A.V[tri(6, i, j)]);
-      A.V[tri(6, i, j)] = fma(jv[i], jv[j], A.V[tri(6, i, j)]);
-    }
-    A.g[i] = fma(eu, ju[i], A.g[i]);
-    A.g[i] = fma(ev, jv[i], A.g[i]);
-  }
-CC_UNROLL
-  for (int a = 0; a < T::NA; ++a) {
-CC_UNROLL
-    for (int c = 0; c < 6; ++c) {
-      A.W[T::ucol(a) * 6 + c] = fma(p.au[a], ju[c], A.W[T::ucol(a) * 6 + c]);
-      A.W[T::vcol(a) * 6 + c] = fma(p.av[a], jv[c], A.W[T::vcol(a) * 6 + c]);
-    }
-  }
+  accumulate_vg(A.V, A.g, ju, jv, eu, ev);
+  accumulate_w(A.W, p, ju, jv);
 }
 
 template <int MODEL>
@@ -362,35 +415,6 @@ CC_UNROLL
   A.v[NU + NI] = fma(ev, ev, A.v[NU + NI]);
 }
 // (pinhole counts cx/cy through its unit columns; add_count is a no-op there)
-
-// Fisheye specialisations: k rows share the 6-vector m6 = m ju + n jv, scaled by t^j.
-CC_HD void accumulate_view(ViewAcc<FISHEYE>& A, const PointEval<FISHEYE>& p, const double Yr[3],
-                           double eu, double ev) {
-  double ju[6], jv[6];
-  pose_row(Yr, p.gu, ju);
-  pose_row(Yr, p.gv, jv);
-  const double xd = p.au[0], yd = p.av[0], m = p.au[2], n = p.av[2], t1 = p.th2;
-  const double t2 = t1 * t1, t3 = t2 * t1;
-  CC_UNROLL
-  for (int i = 0; i < 6; ++i) {
-    CC_UNROLL
-    for (int j = i; j < 6; ++j) {
-      A.V[tri(6, i, j)] = fma(ju[i], ju[j], A.V[tri(6, i, j)]);
-      A.V[tri(6, i, j)] = fma(jv[i], jv[j], A.V[tri(6, i, j)]);
-    }
-    A.g[i] = fma(eu, ju[i], A.g[i]);
-    A.g[i] = fma(ev, jv[i], A.g[i]);
-    A.W[0 * 6 + i] = fma(xd, ju[i], A.W[0 * 6 + i]);
-    A.W[1 * 6 + i] = fma(yd, jv[i], A.W[1 * 6 + i]);
-    A.W[2 * 6 + i] += ju[i];
-    A.W[3 * 6 + i] += jv[i];
-    const double m6 = fma(m, ju[i], n * jv[i]);
-    A.W[4 * 6 + i] += m6;
-    A.W[5 * 6 + i] = fma(t1, m6, A.W[5 * 6 + i]);
-    A.W[6 * 6 + i] = fma(t2, m6, A.W[6 * 6 + i]);
-    A.W[7 * 6 + i] = fma(t3, m6, A.W[7 * 6 + i]);
-  }
-}
 
 CC_HD void accumulate_intr(IntrAcc<FISHEYE>& A, const PointEval<FISHEYE>& p, double eu, double ev) {
   const double xd = p.au[0], yd = p.av[0], m = p.au[2], n = p.av[2], t1 = p.th2;
@@ -457,6 +481,21 @@ CC_HD void to_rodrigues_frame(const double Jl[9], double V[21], double* W, doubl
   const double g0 = g[0], g1 = g[1], g2 = g[2];
   CC_UNROLL
   for (int j = 0; j < 3; ++j) g[j] = Jl[0 * 3 + j] * g0 + Jl[1 * 3 + j] * g1 + Jl[2 * 3 + j] * g2;
+}
+
+// The same map split in two: pose block + gradient, and the cross block.
+CC_HD void vg_to_rodrigues_frame(const double Jl[9], double V[21], double g[6]) {
+  double Wd[6] = {0, 0, 0, 0, 0, 0};
+  to_rodrigues_frame<1>(Jl, V, Wd, g);
+}
+template <int NI>
+CC_HD void w_to_rodrigues_frame(const double Jl[9], double* W) {
+  CC_UNROLL
+  for (int a = 0; a < NI; ++a) {
+    const double w0 = W[a * 6 + 0], w1 = W[a * 6 + 1], w2 = W[a * 6 + 2];
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j) W[a * 6 + j] = w0 * Jl[0 * 3 + j] + w1 * Jl[1 * 3 + j] + w2 * Jl[2 * 3 + j];
+  }
 }
 
 // In-place Cholesky of a 6x6 SPD matrix stored as upper triangle (21): on

@@ -99,9 +99,10 @@ class Engine:
         self.pose = [torch.zeros(6, S, **f64), torch.zeros(6, S, **f64)]
         self.pose[0][5] = 1.0
         self.pose[1][5] = 1.0
-        self.V = torch.zeros(21, S, **f64)
+        # pose blocks are double-buffered (current / trial point), W is not
+        self.Vs = [torch.zeros(21, S, **f64), torch.zeros(21, S, **f64)]
+        self.gs = [torch.zeros(6, S, **f64), torch.zeros(6, S, **f64)]
         self.W = torch.zeros(self.NI * 6, S, **f64)
-        self.g = torch.zeros(6, S, **f64)
         # [U|b|cost] and [C|d] of buffer 0 share one allocation so a full
         # normal-equation evaluation needs a single all-reduce (self.rec)
         self.rec = torch.zeros(self.glob_len + self.schur_len, **f64)
@@ -181,11 +182,34 @@ class Engine:
                    self.pose[pose_idx].data_ptr(), int(max_iter), float(tol), self.iters.data_ptr(),
                    self._stream())
 
-    def intr_normal(self, intr_idx, pose_idx, glob_idx, with_normal=True, view_cost=False):
+    @property
+    def V(self):
+        return self.Vs[0]
+
+    @property
+    def g(self):
+        return self.gs[0]
+
+    def swap_blocks(self):
+        """Trial pose blocks become the current ones."""
+        self.Vs[0], self.Vs[1] = self.Vs[1], self.Vs[0]
+        self.gs[0], self.gs[1] = self.gs[1], self.gs[0]
+
+    def intr_normal(self, intr_idx, pose_idx, glob_idx, with_normal=True, view_cost=False, blocks=None):
+        """Evaluation A.  ``blocks`` = 0/1 also stores V, g into that buffer."""
         self._call("camcal_intr_normal", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
                    self.pose[pose_idx].data_ptr(), 1 if with_normal else 0,
                    self.glob[glob_idx].data_ptr(),
                    self.view_cost.data_ptr() if view_cost else None,
+                   self.Vs[blocks].data_ptr() if blocks is not None else None,
+                   self.gs[blocks].data_ptr() if blocks is not None else None,
+                   self.scratch.data_ptr(), self._stream())
+
+    def cross_schur(self, intr_idx, pose_idx, lam, store_w=True):
+        """Evaluation B at the current point: W (optionally stored) and [C|d]."""
+        self._call("camcal_cross_schur", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), self.Vs[0].data_ptr(), self.gs[0].data_ptr(), float(lam),
+                   self.W.data_ptr() if store_w else None, self.schur.data_ptr(),
                    self.scratch.data_ptr(), self._stream())
 
     def view_blocks(self, intr_idx, pose_idx):
@@ -211,15 +235,14 @@ class Engine:
                    self.pose[pose_out].data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(),
                    self._stream())
 
-    def normal_eq(self, intr_idx, pose_idx, lam, store_blocks=True):
+    def normal_eq(self, intr_idx, pose_idx, lam, store_w=True, fused=False):
         """One full normal-equation evaluation (the benchmarked unit) into
-        ``self.rec`` = [U|b|cost|C|d]; fused single pass over the points."""
-        sb = bool(store_blocks)
-        self._call("camcal_normal_eq", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
-                   self.pose[pose_idx].data_ptr(), float(lam),
-                   self.V.data_ptr() if sb else None, self.W.data_ptr() if sb else None,
-                   self.g.data_ptr() if sb else None, self.glob[0].data_ptr(), self.schur.data_ptr(),
-                   self.scratch.data_ptr(), self._stream())
+        ``self.rec`` = [U|b|cost|C|d]."""
+        name = "camcal_normal_eq_fused" if fused else "camcal_normal_eq"
+        self._call(name, self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), float(lam), self.V.data_ptr(),
+                   self.W.data_ptr() if (store_w or fused) else None, self.g.data_ptr(),
+                   self.glob[0].data_ptr(), self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
 
     def time_stage(self, stage, reps, lam=0.0):
         """Average milliseconds per launch of one stage, HIP events on the

@@ -50,26 +50,33 @@ def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
     """CvLevMarq::updateAlt driven over the Schur-eliminated system.
 
     Expects ``E.intr[0]`` / ``E.pose[0]`` to hold the starting point.  On
-    return buffer 0 holds the result.  Returns (errNorm2, iterations)."""
+    return buffer 0 holds the result.  Returns (errNorm2, iterations).
+
+    Stage use per accepted iteration: evaluation B at the current point (W and
+    the Schur complement for the current lambda), reduced solve, back-
+    substitution, evaluation A at the trial point (cost, U, b and the trial's
+    V, g).  A rejected trial only repeats the cheap stored-block Schur kernel."""
     comm = comm or Comm(enabled=False)
     max_iter = int(min(max(max_iter, 1), 1000))
     eps = max(float(eps), DBL_EPSILON)
     lam_lg10 = -3
     cur, tri = 0, 1
     cost_idx = E.glob_len - 1
-    E.intr_normal(cur, cur, cur, with_normal=True)
+    E.intr_normal(cur, cur, cur, with_normal=True, blocks=0)
     comm.allreduce(E.glob[cur])
     err = float(E.glob[cur][cost_idx].item())
-    E.view_blocks(cur, cur)
     iters = 0
 
-    def step(lam):
-        E.schur_complement(lam)
+    def step(lam, fresh):
+        if fresh:
+            E.cross_schur(cur, cur, lam, store_w=True)
+        else:
+            E.schur_complement(lam)
         comm.allreduce(E.schur)
         E.solve_reduced(cur, mask, lam, -1.0, cur, tri)
         E.backsub(lam, cur, tri)
         comm.allreduce(E.norms)
-        E.intr_normal(tri, tri, tri, with_normal=True)
+        E.intr_normal(tri, tri, tri, with_normal=True, blocks=1)
         comm.allreduce(E.glob[tri])
         # one device->host readback per trial step
         rec = torch.cat([E.glob[tri][cost_idx:cost_idx + 1], E.stats[:5], E.norms]).cpu().numpy()
@@ -77,12 +84,12 @@ def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
 
     while True:
         prev_err = err
-        err, stats, norms = step(10.0 ** lam_lg10)
+        err, stats, norms = step(10.0 ** lam_lg10, True)
         while err > prev_err:
             lam_lg10 += 1
             if lam_lg10 > 16:
                 break
-            err, stats, norms = step(10.0 ** lam_lg10)
+            err, stats, norms = step(10.0 ** lam_lg10, False)
         lam_lg10 = max(lam_lg10 - 1, -16)
         iters += 1
         rel = math.sqrt(stats[0] + norms[0]) / math.sqrt(stats[1] + norms[1])
@@ -90,11 +97,11 @@ def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
         E.intr[cur], E.intr[tri] = E.intr[tri], E.intr[cur]
         E.pose[cur], E.pose[tri] = E.pose[tri], E.pose[cur]
         E.glob[cur].copy_(E.glob[tri])
+        E.swap_blocks()
         if log is not None:
             log.append(dict(iter=iters, err=err, rel=rel, lam_lg10=lam_lg10))
         if iters >= max_iter or rel < eps:
             return err, iters
-        E.view_blocks(cur, cur)
 
 
 def gn_fisheye(E, mask, criteria, recompute_extrinsic=True, comm=None, log=None):
@@ -110,11 +117,8 @@ def gn_fisheye(E, mask, criteria, recompute_extrinsic=True, comm=None, log=None)
            (ctype == 3 and (change <= eps or it >= maxc)):
             break
         alpha2 = 1.0 - 0.6 ** (it + 1.0)
-        E.intr_normal(0, 0, 0, with_normal=True)
-        comm.allreduce(E.glob[0])
-        E.view_blocks(0, 0)
-        E.schur_complement(0.0)
-        comm.allreduce(E.schur)
+        E.normal_eq(0, 0, 0.0, store_w=False)
+        comm.allreduce(E.rec)
         E.solve_reduced(0, mask, 0.0, -alpha2, 0, 0)
         st = E.stats[:5].cpu().numpy()
         change = math.sqrt(st[2]) / math.sqrt(st[3])

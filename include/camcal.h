@@ -90,14 +90,25 @@ int camcal_pose_init(int model, const camcal_tiles* tiles, const double* intr, d
 int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr, double* pose,
                        int max_iter, double tol, int32_t* iters, void* stream);
 
-/* Normal-equation evaluation, intrinsic part (cvCalibrateCamera2Internal's
- * JtJ(0:NI,0:NI), JtErr(0:NI), errNorm; fisheye ComputeJacobians' A A^T, A e).
+/* Evaluation A -- cost, intrinsic normal block and pose blocks
+ * (cvCalibrateCamera2Internal's JtJ(0:NI,0:NI), JtErr(0:NI), errNorm,
+ * JtJ(ext,ext), JtErr(ext); fisheye ComputeJacobians' A A^T, A e, B B^T, B e).
  * with_normal = 0 computes the cost only (CvLevMarq CHECK_ERR pass).
- * glob receives camcal_glob_len doubles; view_cost (optional, may be NULL)
- * receives the sum of squared residuals of every slot. */
+ * glob receives camcal_glob_len doubles.  view_cost (optional) receives the
+ * sum of squared residuals of every slot.  V, g (both or neither; need
+ * with_normal = 1) receive the per-view 6x6 block and gradient in Rodrigues
+ * coordinates. */
 int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
                        const double* pose, int with_normal, double* glob, double* view_cost,
-                       double* scratch, void* stream);
+                       double* V, double* g, double* scratch, void* stream);
+
+/* Evaluation B -- cross blocks and their elimination: W = Ji^T Je per view
+ * (JtJ(0:NI,ext) / A B^T), then C = sum W V'^-1 W^T, d = sum W V'^-1 g with the
+ * V, g of evaluation A and V' = V, diag*(1+lam).  W_out (optional) keeps the
+ * blocks for camcal_schur / camcal_backsub at other lam. */
+int camcal_cross_schur(int model, const camcal_tiles* tiles, const double* intr,
+                       const double* pose, const double* V, const double* g, double lam,
+                       double* W_out, double* schur, double* scratch, void* stream);
 
 /* Normal-equation evaluation, per-view part: V = Je^T Je, W = Ji^T Je,
  * g = Je^T e in Rodrigues coordinates (the B B^T, A B^T, B e blocks of
@@ -131,19 +142,26 @@ int camcal_backsub(int model, const camcal_tiles* tiles, const double* V, const 
                    const double* g, double lam, const double* dK, const double* pose_in,
                    double* pose_out, double* norms, double* scratch, void* stream);
 
-/* One full normal-equation evaluation (the unit the benchmark times): same
- * results as camcal_intr_normal(with_normal=1) + camcal_view_blocks +
- * camcal_schur.  When `schur == glob + camcal_glob_len(model)` (one contiguous
- * record) it runs as ONE fused pass over the points; V, W, g may then all be
- * NULL to skip storing the per-view blocks (Gauss-Newton callers that never
- * back-substitute). */
+/* One full normal-equation evaluation (the unit the benchmark times) =
+ * camcal_intr_normal(with V, g) + camcal_cross_schur: two passes over the
+ * points, each holding half of the accumulators in registers.  V, g are
+ * required (scratch for the hand-over), W may be NULL. */
 int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr,
                      const double* pose, double lam, double* V, double* W, double* g,
                      double* glob, double* schur, double* scratch, void* stream);
 
+/* Same results from ONE pass over the points with every accumulator of a view
+ * in one lane (kept for comparison: it runs at one wavefront per SIMD and is
+ * slower on gfx950).  Needs schur == glob + camcal_glob_len;
+ * V, W, g all NULL or all set. */
+int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* intr,
+                           const double* pose, double lam, double* V, double* W, double* g,
+                           double* glob, double* schur, double* scratch, void* stream);
+
 /* Timing helper for benchmarks: average duration in milliseconds of `reps`
  * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,
- * 2 = schur, 3 = the fused camcal_normal_eq), measured with HIP events on `stream`. */
+ * 2 = schur, 3 = camcal_normal_eq, 4 = camcal_normal_eq_fused, 5 = cross_schur),
+ * measured with HIP events on `stream`. */
 int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
                       const double* intr, const double* pose, double lam, double* V, double* W,
                       double* g, double* glob, double* schur, double* scratch, void* stream,

@@ -28,8 +28,10 @@ inline void load_pose(const double* pose, int64_t S, int64_t slot, double p[6]) 
   for (int c = 0; c < 6; ++c) p[c] = pose[c * S + slot];
 }
 
-template <int MODEL, bool NORMAL>
-void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, double* glob, double* view_cost) {
+template <int MODEL, int MODE>
+void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, double* glob, double* view_cost,
+                 double* Vb, double* gb) {
+  constexpr bool NORMAL = MODE > 0;
   constexpr int NV = IntrAcc<MODEL>::NV, NR = IntrAcc<MODEL>::NR;
   std::vector<double> tot(NR, 0.0);
   for (int tile = 0; tile < t->n_tiles; ++tile) {
@@ -39,9 +41,14 @@ void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, 
       load_pose(pose, t->n_slots, slot, p);
       IntrAcc<MODEL> acc;
       acc.zero();
-      const double vc = t->planar ? lane_intr_normal<MODEL, NORMAL, true>(lane_tile(t, tile, lane), intr, p, acc)
-                                  : lane_intr_normal<MODEL, NORMAL, false>(lane_tile(t, tile, lane), intr, p, acc);
+      double V[21], g[6];
+      const double vc = t->planar ? lane_intr_normal<MODEL, MODE, true>(lane_tile(t, tile, lane), intr, p, acc, V, g)
+                                  : lane_intr_normal<MODEL, MODE, false>(lane_tile(t, tile, lane), intr, p, acc, V, g);
       if (view_cost) view_cost[slot] = vc;
+      if (MODE == 2) {
+        for (int e = 0; e < 21; ++e) Vb[e * t->n_slots + slot] = V[e];
+        for (int e = 0; e < 6; ++e) gb[e * t->n_slots + slot] = g[e];
+      }
       for (int i = 0; i < NR; ++i) tot[i] += acc.v[i];
     }
   }
@@ -127,6 +134,30 @@ void pose_init(const camcal_tiles* t, const double* intr, double* pose, int32_t*
       if (status) status[slot] = tv.n == 0 ? 0 : st;
     }
 }
+template <int MODEL>
+static void cross_schur(const camcal_tiles* t, const double* intr, const double* pose, const double* Vb,
+                        const double* gb, double lam, double* Wb, double* out) {
+  constexpr int NI = MT<MODEL>::NI, NS = trisz(NI) + NI;
+  const int64_t S = t->n_slots;
+  double acc[NS];
+  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int lane = 0; lane < LANES; ++lane) {
+      const int64_t slot = (int64_t)tile * LANES + lane;
+      double p[6], W[NI * 6];
+      load_pose(pose, S, slot, p);
+      const LaneTile tv = lane_tile(t, tile, lane);
+      if (t->planar) lane_cross_block<MODEL, true>(tv, intr, p, W); else lane_cross_block<MODEL, false>(tv, intr, p, W);
+      if (Wb) for (int e = 0; e < NI * 6; ++e) Wb[e * S + slot] = W[e];
+      if (tv.n > 0) {
+        double V[21], g[6];
+        for (int e = 0; e < 21; ++e) V[e] = Vb[e * S + slot];
+        for (int e = 0; e < 6; ++e) g[e] = gb[e * S + slot];
+        lane_schur_regs<NI>(V, W, g, lam, acc);
+      }
+    }
+  for (int i = 0; i < NS; ++i) out[i] = acc[i];
+}
 }  // namespace
 
 extern "C" {
@@ -167,9 +198,23 @@ int camcal_pose_refine(int model, const camcal_tiles* t, const double* intr, dou
   return 0;
 }
 int camcal_intr_normal(int model, const camcal_tiles* t, const double* intr, const double* pose, int with_normal,
-                       double* glob, double* view_cost, double*, void*) {
-  if (model == 0) { if (with_normal) intr_normal<PINHOLE, true>(t, intr, pose, glob, view_cost); else intr_normal<PINHOLE, false>(t, intr, pose, glob, view_cost); }
-  else { if (with_normal) intr_normal<FISHEYE, true>(t, intr, pose, glob, view_cost); else intr_normal<FISHEYE, false>(t, intr, pose, glob, view_cost); }
+                       double* glob, double* view_cost, double* V, double* g, double*, void*) {
+  const int mode = !with_normal ? 0 : (V ? 2 : 1);
+  if (model == 0) {
+    if (mode == 2) intr_normal<PINHOLE, 2>(t, intr, pose, glob, view_cost, V, g);
+    else if (mode == 1) intr_normal<PINHOLE, 1>(t, intr, pose, glob, view_cost, V, g);
+    else intr_normal<PINHOLE, 0>(t, intr, pose, glob, view_cost, V, g);
+  } else {
+    if (mode == 2) intr_normal<FISHEYE, 2>(t, intr, pose, glob, view_cost, V, g);
+    else if (mode == 1) intr_normal<FISHEYE, 1>(t, intr, pose, glob, view_cost, V, g);
+    else intr_normal<FISHEYE, 0>(t, intr, pose, glob, view_cost, V, g);
+  }
+  return 0;
+}
+int camcal_cross_schur(int model, const camcal_tiles* t, const double* intr, const double* pose, const double* V,
+                       const double* g, double lam, double* W_out, double* schur, double*, void*) {
+  if (model == 0) cross_schur<PINHOLE>(t, intr, pose, V, g, lam, W_out, schur);
+  else cross_schur<FISHEYE>(t, intr, pose, V, g, lam, W_out, schur);
   return 0;
 }
 int camcal_view_blocks(int model, const camcal_tiles* t, const double* intr, const double* pose, double* V, double* W,
@@ -189,7 +234,12 @@ int camcal_backsub(int model, const camcal_tiles* t, const double* V, const doub
 }
 int camcal_normal_eq(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam, double* V,
                      double* W, double* g, double* glob, double* schur_out, double* scratch, void* s) {
-  camcal_intr_normal(model, t, intr, pose, 1, glob, nullptr, scratch, s);
+  camcal_intr_normal(model, t, intr, pose, 1, glob, nullptr, V, g, scratch, s);
+  return camcal_cross_schur(model, t, intr, pose, V, g, lam, W, schur_out, scratch, s);
+}
+int camcal_normal_eq_fused(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam,
+                           double* V, double* W, double* g, double* glob, double* schur_out, double* scratch, void* s) {
+  camcal_intr_normal(model, t, intr, pose, 1, glob, nullptr, nullptr, nullptr, scratch, s);
   std::vector<double> tV, tW, tg;
   if (!V) {
     tV.resize(21 * t->n_slots); tW.resize(54 * t->n_slots); tg.resize(6 * t->n_slots);

@@ -14,7 +14,7 @@ E.set_intr(0, P.intr_guess())
 E.pose_init(0, 0); E.pose_refine(0, 0, 20, 1e-10)
 torch.cuda.synchronize()
 for rnd in range(3):
-    for st, nm in ((0, 'intr_normal'), (1, 'view_blocks'), (2, 'schur'), (3, 'fused_normal_eq')):
+    for st, nm in ((0, 'evalA'), (5, 'evalB_cross_schur'), (3, 'normal_eq'), (4, 'fused_normal_eq')):
         E.time_stage(st, 2)
         ms = E.time_stage(st, 20)
         print(f'{cfg} {nv} {nm}: {ms:.4f} ms -> {P.n_obs/ms*1e3:.3e} obs/s', flush=True)
