@@ -653,7 +653,7 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
     else if (stage == 1) rc = camcal_view_blocks(model, tiles, intr, pose, V, W, g, stream);
     else if (stage == 2) rc = camcal_schur(model, tiles, V, W, g, lam, schur, scratch, stream);
     else if (stage == 3) rc = camcal_normal_eq(model, tiles, intr, pose, lam, V, W, g, glob, schur, scratch, stream);
-    else if (stage == 4) rc = camcal_normal_eq_fused(model, tiles, intr, pose, lam, V, W, g, glob, schur, scratch, stream);
+    else if (stage == 4) rc = camcal_normal_eq_fused(model, tiles, intr, pose, lam, nullptr, nullptr, nullptr, glob, schur, scratch, stream);
     else rc = camcal_cross_schur(model, tiles, intr, pose, V, g, lam, nullptr, schur, scratch, stream);
   }
   HIP_TRY(hipEventRecord(e1, s));

@@ -235,18 +235,27 @@ class Engine:
                    self.pose[pose_out].data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(),
                    self._stream())
 
-    def normal_eq(self, intr_idx, pose_idx, lam, store_w=True, fused=False):
+    def normal_eq(self, intr_idx, pose_idx, lam, store_blocks=True, fused=False):
         """One full normal-equation evaluation (the benchmarked unit) into
-        ``self.rec`` = [U|b|cost|C|d]."""
-        name = "camcal_normal_eq_fused" if fused else "camcal_normal_eq"
-        self._call(name, self.model, self._tp(), self.intr[intr_idx].data_ptr(),
-                   self.pose[pose_idx].data_ptr(), float(lam), self.V.data_ptr(),
-                   self.W.data_ptr() if (store_w or fused) else None, self.g.data_ptr(),
-                   self.glob[0].data_ptr(), self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
+        ``self.rec`` = [U|b|cost|C|d].  ``fused``: single pass over the points
+        (camcal_normal_eq_fused), else evaluation A + evaluation B."""
+        if fused:
+            sb = bool(store_blocks)
+            self._call("camcal_normal_eq_fused", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                       self.pose[pose_idx].data_ptr(), float(lam),
+                       self.V.data_ptr() if sb else None, self.W.data_ptr() if sb else None,
+                       self.g.data_ptr() if sb else None,
+                       self.glob[0].data_ptr(), self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
+        else:
+            self._call("camcal_normal_eq", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                       self.pose[pose_idx].data_ptr(), float(lam), self.V.data_ptr(),
+                       self.W.data_ptr() if store_blocks else None, self.g.data_ptr(),
+                       self.glob[0].data_ptr(), self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
 
     def time_stage(self, stage, reps, lam=0.0):
         """Average milliseconds per launch of one stage, HIP events on the
-        current stream (0 intr_normal, 1 view_blocks, 2 schur)."""
+        current stream (0 evaluation A, 1 view_blocks, 2 schur from stored blocks,
+        3 normal_eq = A + B, 4 fused single-pass normal_eq, 5 evaluation B)."""
         ms = C.c_float(0.0)
         self._call("camcal_time_stage", int(stage), int(reps), self.model, self._tp(),
                    self.intr[0].data_ptr(), self.pose[0].data_ptr(), float(lam), self.V.data_ptr(),

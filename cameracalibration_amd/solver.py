@@ -117,7 +117,7 @@ def gn_fisheye(E, mask, criteria, recompute_extrinsic=True, comm=None, log=None)
            (ctype == 3 and (change <= eps or it >= maxc)):
             break
         alpha2 = 1.0 - 0.6 ** (it + 1.0)
-        E.normal_eq(0, 0, 0.0, store_w=False)
+        E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
         comm.allreduce(E.rec)
         E.solve_reduced(0, mask, 0.0, -alpha2, 0, 0)
         st = E.stats[:5].cpu().numpy()

@@ -160,7 +160,7 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
 
 /* Timing helper for benchmarks: average duration in milliseconds of `reps`
  * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,
- * 2 = schur, 3 = camcal_normal_eq, 4 = camcal_normal_eq_fused, 5 = cross_schur),
+ * 2 = schur, 3 = camcal_normal_eq, 4 = camcal_normal_eq_fused without block stores, 5 = cross_schur),
  * measured with HIP events on `stream`. */
 int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
                       const double* intr, const double* pose, double lam, double* V, double* W,
