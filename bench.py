@@ -34,7 +34,7 @@ from cameracalibration_amd.engine import Engine  # noqa: E402
 # Algorithmic work model (BASELINE.md section 3 / SURVEY.md 8d; re-counted in DESIGN.md)
 FLOP_PER_OBS = {"fisheye": 605.0, "pinhole": 732.0}
 FLOP_PER_VIEW = 1200.0
-BYTES_PER_OBS = 20.0
+BYTES_PER_OBS = 20.0      # X Y Z u v float32 (the planar fast path reads 16: Z rows are skipped)
 BYTES_PER_VIEW = 696.0
 PEAK_FP64_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 FMA lanes x 2 flop x 2.4 GHz (vector FP64)
 PEAK_HBM_GBS = 8000.0
@@ -147,6 +147,14 @@ def main():
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(res))
             probe[key] = float(res.value) if rc == 0 else None
         del buf
+        # HBM traffic of the step's kernel from the committed rocprofv3 PMC passes (scaled by
+        # observation count; null when the profile file is absent)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(HERE, "profiles", "pmc_traffic.json")))
+            traffic = tj["k_normal_fused<fisheye,no block stores,planar>"]["hbm_bytes"] * n_obs / tj["workload_obs"]
+        except Exception:
+            pass
         out = {
             "metric": "corner-obs/s for residual+Jacobian+Schur (one normal-equation evaluation)",
             "value": world * n_obs * args.steps / el,
@@ -160,7 +168,7 @@ def main():
                        "views_per_gpu": n_views, "obs_per_gpu": n_obs, "parallelism": f"views sharded x{world}"},
             "roofline": {
                 "bound": "fp64-valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
                 "kernels_ms": stage_ms, "pass_ms": pass_ms,
                 "work_model": "605 flop/obs + 1200 flop/view (BASELINE.md section 3) over the single-pass "
                               "kernel k_normal_fused (+ its two tiny reduction launches)",
@@ -168,7 +176,7 @@ def main():
                 "frac_of_measured_peak": (ach_tf / probe["fp64_fma_tflops"]) if probe.get("fp64_fma_tflops") else None,
             },
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": ach_gb / PEAK_HBM_GBS, "traffic": None,
+                             "frac": ach_gb / PEAK_HBM_GBS, "traffic": traffic,
                              "measured_peak_read_gbs": probe.get("hbm_read_gbs"),
                              "work_model": "20 B/obs + 696 B/view"},
         }

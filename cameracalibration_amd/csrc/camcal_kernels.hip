@@ -422,6 +422,14 @@ __global__ __launch_bounds__(TPB) void k_peak_read(const float4* __restrict__ in
   if (acc == 123.456f) out[0] = acc;
 }
 
+// one float per lane, 256-byte rows: the access shape of the point loads (PMC calibration)
+__global__ __launch_bounds__(TPB) void k_peak_read4(const float* __restrict__ in, size_t n, float* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += in[i];
+  if (acc == 123.456f) out[0] = acc;
+}
+
 inline int tiles_ok(const camcal_tiles* t) {
   if (!t || t->n_tiles <= 0 || t->n_slots != (int64_t)t->n_tiles * LANES) return 0;
   if (!t->tile_off || !t->tile_nmax || !t->lane_n) return 0;
@@ -678,7 +686,8 @@ int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream
     HIP_TRY(hipEventRecord(e0, s));
     for (int r = 0; r < reps; ++r) {
       if (kind == 0) hipLaunchKernelGGL(k_peak_fma, dim3(blocks), dim3(TPB), 0, s, (double*)buf, iters, 0.999999, 1e-7);
-      else hipLaunchKernelGGL(k_peak_read, dim3(256 * 16), dim3(TPB), 0, s, (const float4*)buf, (size_t)bytes / 16, (float*)buf);
+      else if (kind == 1) hipLaunchKernelGGL(k_peak_read, dim3(256 * 16), dim3(TPB), 0, s, (const float4*)buf, (size_t)bytes / 16, (float*)buf);
+      else hipLaunchKernelGGL(k_peak_read4, dim3(256 * 16), dim3(TPB), 0, s, (const float*)buf, (size_t)bytes / 4, (float*)buf);
     }
     HIP_TRY(hipEventRecord(e1, s));
     HIP_TRY(hipEventSynchronize(e1));

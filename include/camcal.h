@@ -168,7 +168,8 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
                       float* ms_out_host);
 
 /* Peak probes for the roofline report: kind 0 = dependent-free FP64 FMA stream
- * (result TFLOP/s), kind 1 = streaming read of `bytes` from buf (result GB/s).
+ * (result TFLOP/s), kind 1 = streaming read of `bytes` from buf with 16-byte loads
+ * (result GB/s), kind 2 = the same with 4-byte loads (PMC calibration of the point-load shape).
  * buf: device scratch of at least `bytes` (>= 4096).  No reference counterpart. */
 int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream,
                       double* result_host);
