@@ -11,6 +11,9 @@ Use it where the reference uses cv2 for calibration::
         flags=cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC
               | cc.CALIB_USE_INTRINSIC_GUESS, criteria=...)
 
+``cc.calibrate_rig`` (rig.py) is the joint multi-camera solve of BASELINE.json
+config 4, which the reference does not have.
+
 (reference call sites: server/aruco/camera_calib.py:74-77,153-156 and
 server/internal/IntrinsicCalibration/intrinsicCalib.py:102-105,131-134,194-197,223-226).
 """
@@ -23,5 +26,6 @@ from .api import (  # noqa: F401
     CALIB_FIX_S1_S2_S3_S4, CALIB_TILTED_MODEL, CALIB_FIX_TAUX_TAUY, CALIB_FIX_TANGENT_DIST,
 )
 from . import fisheye  # noqa: F401
+from .rig import calibrate_rig  # noqa: F401
 
-__all__ = ["calibrateCamera", "fisheye", "error", "set_device"]
+__all__ = ["calibrateCamera", "fisheye", "calibrate_rig", "error", "set_device"]

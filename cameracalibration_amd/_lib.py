@@ -45,6 +45,11 @@ _SIGNATURES = {
     "camcal_normal_eq_fused": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_float)]),
+    "camcal_rig_compose": (C.c_int, [_TP, _P, _P, C.c_int64, _P, _P, _P]),
+    "camcal_rig_local_blocks": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "camcal_rig_assemble": (C.c_int, [_I, _TP, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "camcal_rig_pose_schur": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P]),
+    "camcal_rig_backsub": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
     "camcal_peak_probe": (C.c_int, [_I, _P, C.c_int64, _I, _P, C.POINTER(C.c_double)]),
 }
 

@@ -14,6 +14,7 @@
 
 #include "../../include/camcal.h"
 #include "camcal_lane.h"
+#include "camcal_rig.h"
 
 using namespace camcal;
 
@@ -22,7 +23,7 @@ namespace {
 constexpr int TPB = 256;                 // 4 wavefronts per workgroup
 constexpr int WPB = TPB / LANES;
 constexpr int MAX_WAVES = 4096;          // persistent waves of a reducing kernel (16 per CU)
-constexpr int MAX_NV = 64;               // widest reduced record (pinhole: 45 + 9 + 1 = 55)
+constexpr int MAX_NV = 96;               // widest reduced record (rig assemble, pinhole: 54 + 21 + 6 = 81)
 
 #define DISPATCH_MODEL_PLANAR(model, planar, L)                       \
   do {                                                                \
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(TPB) void k_cross_schur(camcal_tiles t, const doubl
 // Fused normal-equation evaluation: U, b, cost + per-view blocks + Schur
 // complement in one pass over the points.  One tile per wavefront; the wave's
 // partial record [U|b|cost|C|d] goes to scratch[i][tile] (second stage sums).
-template <int MODEL, bool WRITE_BLOCKS, bool PLANAR>
+template <int MODEL, bool WRITE_BLOCKS, bool PLANAR, bool LOCAL = false>
 __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const double* __restrict__ intr,
                                                       const double* __restrict__ pose, double lam,
                                                       double* __restrict__ Vb, double* __restrict__ Wb,
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   ViewAcc<MODEL> acc;
   IntrAcc<MODEL> gacc;
   gacc.zero();
-  lane_normal_fused<MODEL, PLANAR>(tv, I, p, acc, gacc);
+  lane_normal_fused<MODEL, PLANAR, LOCAL>(tv, I, p, acc, gacc);
   if (WRITE_BLOCKS) {
 #pragma unroll
     for (int e = 0; e < 21; ++e) Vb[e * S + slot] = acc.V[e];
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
     const double s = wave_sum(gacc.v[i]);
     if (lane == 0) scratch[(size_t)i * scratch_stride + tile] = s;
   }
+  if (LOCAL) return;                      // rig solver: elimination happens per board pose
   double sacc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
@@ -243,6 +245,128 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
     const double s = wave_sum(sacc[i]);
     if (lane == 0) scratch[(size_t)(NG + i) * scratch_stride + tile] = s;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Rig kernels (see camcal_rig.h)
+__global__ __launch_bounds__(TPB) void k_rig_compose(int64_t S, const int32_t* __restrict__ slot_pose,
+                                                     const double* __restrict__ rig_pose, int64_t P,
+                                                     const double* __restrict__ ext, double* __restrict__ pose_out) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= S) return;
+  const int idx = slot_pose[slot];
+  double out[6] = {0, 0, 0, 0, 0, 1};
+  if (idx >= 0) {
+    double pp[6], e[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { pp[c] = rig_pose[c * P + idx]; e[c] = ext[c]; }
+    rig_compose(pp, e, out);
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) pose_out[c * S + slot] = out[c];
+}
+
+template <int NI>
+__global__ __launch_bounds__(TPB) void k_rig_assemble(int64_t S, int n_tiles, const int32_t* __restrict__ slot_pose,
+                                                      const double* __restrict__ rig_pose, int64_t P,
+                                                      const double* __restrict__ ext, const double* __restrict__ Vb,
+                                                      const double* __restrict__ Wb, const double* __restrict__ gb,
+                                                      double* __restrict__ Vp, double* __restrict__ gp,
+                                                      double* __restrict__ Wp, double* __restrict__ scratch) {
+  constexpr int NACC = NI * 6 + 21 + 6;
+  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * WPB;
+  const int lane = threadIdx.x & 63;
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  double e[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) e[c] = ext[c];
+  for (int tile = wave; tile < n_tiles; tile += n_waves) {
+    const int64_t slot = (int64_t)tile * LANES + lane;
+    const int idx = slot_pose[slot];
+    if (idx < 0) continue;
+    double pp[6], A[36], B[36], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) Vl[i] = Vb[i * S + slot];
+#pragma unroll
+    for (int i = 0; i < NI * 6; ++i) Wl[i] = Wb[i * S + slot];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gl[i] = gb[i * S + slot];
+    rig_chain(pp, e, A, B);
+    rig_assemble_view<NI>(Vl, Wl, gl, A, B, oV, og, oW, acc);
+#pragma unroll
+    for (int i = 0; i < 21; ++i) Vp[i * P + idx] = oV[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
+#pragma unroll
+    for (int i = 0; i < (NI + 6) * 6; ++i) Wp[i * P + idx] = oW[i];
+  }
+  wave_reduce_store<NACC>(acc, scratch, wave);
+}
+
+template <int G>
+__global__ __launch_bounds__(TPB) void k_rig_pose_schur(int n_cams, int64_t P, const double* __restrict__ Vp_all,
+                                                        const double* __restrict__ gp_all,
+                                                        const double* __restrict__ Wp_all, double lam,
+                                                        double* __restrict__ Y, double* __restrict__ z) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double U[21], g[6];
+  const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, g);
+  const int64_t ld = (int64_t)n_cams * G;
+  if (ok) chol6_fwd(U, g);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) z[p * 6 + k] = ok ? g[k] : 0.0;
+  for (int c = 0; c < n_cams; ++c) {
+    for (int a = 0; a < G; ++a) {
+      double y[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) y[k] = Wp_all[(((int64_t)c * G + a) * 6 + k) * P + p];
+      if (ok) chol6_fwd(U, y);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Y[(p * 6 + k) * ld + c * G + a] = ok ? y[k] : 0.0;
+    }
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(TPB) void k_rig_backsub(int n_cams, int64_t P, const double* __restrict__ Vp_all,
+                                                     const double* __restrict__ gp_all,
+                                                     const double* __restrict__ Wp_all, double lam,
+                                                     const double* __restrict__ dG, const double* __restrict__ pose_in,
+                                                     double* __restrict__ pose_out, double* __restrict__ scratch) {
+  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * WPB;
+  const int lane = threadIdx.x & 63;
+  double acc[2] = {0.0, 0.0};
+  for (int64_t p = (int64_t)wave * LANES + lane; p < P; p += (int64_t)n_waves * LANES) {
+    double U[21], rhs[6], prev[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) prev[k] = pose_in[k * P + p];
+    const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, rhs);
+    if (ok) {
+      for (int c = 0; c < n_cams; ++c)
+        for (int a = 0; a < G; ++a) {
+          const double d = dG[c * G + a];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) rhs[k] -= Wp_all[(((int64_t)c * G + a) * 6 + k) * P + p] * d;
+        }
+      chol6_fwd(U, rhs);
+      chol6_bwd(U, rhs);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double d = ok ? rhs[k] : 0.0;
+      pose_out[k * P + p] = prev[k] - d;
+      acc[0] += d * d;
+      acc[1] += prev[k] * prev[k];
+    }
+  }
+  wave_reduce_store<2>(acc, scratch, wave);
 }
 
 __global__ __launch_bounds__(TPB) void k_finalize_strided(const double* __restrict__ scratch, int n_part, int stride,
@@ -672,6 +796,90 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
   (void)hipEventDestroy(e1);
   *ms_out_host = ms / reps;
   return rc;
+}
+
+int camcal_rig_compose(const camcal_tiles* tiles, const int32_t* slot_pose, const double* rig_pose, int64_t P,
+                       const double* ext, double* pose_out, void* stream) {
+  if (!tiles_ok(tiles) || !slot_pose || !rig_pose || P <= 0 || !ext || !pose_out) return CAMCAL_E_BADARG;
+  const int64_t S = tiles->n_slots;
+  hipLaunchKernelGGL(k_rig_compose, dim3((unsigned)((S + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, S,
+                     slot_pose, rig_pose, P, ext, pose_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_rig_local_blocks(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double* V,
+                            double* W, double* g, double* glob, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !V || !W || !g || !glob || !scratch) return CAMCAL_E_BADARG;
+  const int ng = camcal_glob_len(model);
+  if (ng < 0) return ng;
+  const dim3 gr(grid_tiles(tiles)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  const int nt = tiles->n_tiles;
+  const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
+  double* red = scratch + (size_t)nr * nt;
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P, true>), gr, b, 0, s, *tiles, intr, pose, 0.0, V, W, g, scratch, nt)
+  DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize_strided, dim3(nr), dim3(TPB), 0, s, scratch, nt, nt, red);
+  HIP_TRY(hipGetLastError());
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, 0, 0);
+  else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, 0, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_rig_assemble(int model, const camcal_tiles* tiles, const int32_t* slot_pose, const double* rig_pose,
+                        int64_t P, const double* ext, const double* V, const double* W, const double* g, double* Vp,
+                        double* gp, double* Wp, double* rec_ext, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !slot_pose || !rig_pose || P <= 0 || !ext || !V || !W || !g || !Vp || !gp || !Wp || !rec_ext ||
+      !scratch)
+    return CAMCAL_E_BADARG;
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(Vp, 0, sizeof(double) * 21 * P, s));
+  HIP_TRY(hipMemsetAsync(gp, 0, sizeof(double) * 6 * P, s));
+  HIP_TRY(hipMemsetAsync(Wp, 0, sizeof(double) * (ni + 6) * 6 * P, s));
+  const int gp_ = grid_persistent(tiles);
+  if (ni == 9) hipLaunchKernelGGL(k_rig_assemble<9>, dim3(gp_), dim3(TPB), 0, s, tiles->n_slots, tiles->n_tiles, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, scratch);
+  else hipLaunchKernelGGL(k_rig_assemble<8>, dim3(gp_), dim3(TPB), 0, s, tiles->n_slots, tiles->n_tiles, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, scratch);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize, dim3(ni * 6 + 27), dim3(TPB), 0, s, scratch, gp_ * WPB, rec_ext);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
+                          const double* Wp_all, double lam, double* Y, double* z, void* stream) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  if (n_cams <= 0 || P <= 0 || !Vp_all || !gp_all || !Wp_all || !Y || !z) return CAMCAL_E_BADARG;
+  const dim3 gr((unsigned)((P + TPB - 1) / TPB)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (ni == 9) hipLaunchKernelGGL(k_rig_pose_schur<15>, gr, b, 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, Y, z);
+  else hipLaunchKernelGGL(k_rig_pose_schur<14>, gr, b, 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, Y, z);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
+                       const double* Wp_all, double lam, const double* dG, const double* pose_in, double* pose_out,
+                       double* norms, double* scratch, void* stream) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  if (n_cams <= 0 || P <= 0 || !Vp_all || !gp_all || !Wp_all || !dG || !pose_in || !pose_out || !norms || !scratch)
+    return CAMCAL_E_BADARG;
+  int64_t nb = (P + TPB - 1) / TPB;
+  if (nb > MAX_WAVES / WPB) nb = MAX_WAVES / WPB;
+  hipStream_t s = (hipStream_t)stream;
+  if (ni == 9) hipLaunchKernelGGL(k_rig_backsub<15>, dim3((unsigned)nb), dim3(TPB), 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, dG, pose_in, pose_out, scratch);
+  else hipLaunchKernelGGL(k_rig_backsub<14>, dim3((unsigned)nb), dim3(TPB), 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, dG, pose_in, pose_out, scratch);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize, dim3(2), dim3(TPB), 0, s, scratch, (int)nb * WPB, norms);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream, double* result_host) {

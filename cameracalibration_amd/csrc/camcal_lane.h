@@ -53,7 +53,8 @@ CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double
 // ---------------------------------------------------------------------------
 // K1+K2 fused: one pass over the view's corners feeding both accumulator sets
 // (projection and Jacobian evaluated once per observation).
-template <int MODEL, bool PLANAR>
+// LOCAL: leave the blocks in the local tangent frame of the pose (rig solver).
+template <int MODEL, bool PLANAR, bool LOCAL = false>
 CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const double pose[6],
                              ViewAcc<MODEL>& acc, IntrAcc<MODEL>& gacc) {
   double R[9];
@@ -75,9 +76,11 @@ CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const doubl
     cur = nxt;
   }
   gacc.add_count(tv.n);
-  double Jl[9];
-  left_jacobian(pose, Jl);
-  to_rodrigues_frame<MT<MODEL>::NI>(Jl, acc.V, acc.W, acc.g);
+  if (!LOCAL) {
+    double Jl[9];
+    left_jacobian(pose, Jl);
+    to_rodrigues_frame<MT<MODEL>::NI>(Jl, acc.V, acc.W, acc.g);
+  }
 }
 
 // Schur contribution of one view from blocks held in registers (consumes V, W, g).

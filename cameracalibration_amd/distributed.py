@@ -35,3 +35,17 @@ def shard_lists(object_points, image_points, rank, world):
     n = [len(o) for o in object_points]
     lo, hi = shard_ranges(n, world)[rank]
     return list(object_points[lo:hi]), list(image_points[lo:hi]), (lo, hi)
+
+
+def shard_rig_lists(object_points, image_points, rank, world):
+    """This rank's slice of rig inputs (objectPoints[c][p]): board poses are
+    split into contiguous ranges balanced by the observations all cameras hold
+    of them, so every camera's view of a pose stays on one rank."""
+    P = len(object_points[0])
+    n = np.zeros(P, dtype=np.int64)
+    for cam in object_points:
+        for p, o in enumerate(cam):
+            if o is not None:
+                n[p] += len(o)
+    lo, hi = shard_ranges(n, world)[rank]
+    return ([list(cam[lo:hi]) for cam in object_points], [list(cam[lo:hi]) for cam in image_points], (lo, hi))

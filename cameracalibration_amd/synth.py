@@ -262,9 +262,124 @@ def make_problem(model, n_views, board, size, K_true, D_true, K_guess, D_guess, 
                    meta=dict(seed=seed, noise=noise, board=(int(nb),), ragged=ragged))
 
 
+@dataclass
+class RigProblem:
+    """Config C4: cameras sharing board poses.  Per camera c the views it sees:
+    ``pose_idx[c]`` (n_views_c,) board-pose index of each view, CSR ``view_ptr[c]``,
+    ``obj[c]`` / ``img[c]`` float32 points."""
+    model: str
+    image_size: tuple
+    n_poses: int
+    intr_true: np.ndarray          # (n_cams, NI)
+    intr_guess: np.ndarray         # (n_cams, NI)
+    ext_true: np.ndarray           # (n_cams, 6)  camera-from-rig (rvec, tvec); camera 0 = 0
+    poses_true: np.ndarray         # (P, 6)       rig-from-board
+    pose_idx: list
+    view_ptr: list
+    obj: list
+    img: list
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_cams(self):
+        return len(self.pose_idx)
+
+    @property
+    def n_obs(self):
+        return int(sum(int(v[-1]) for v in self.view_ptr))
+
+    def as_lists(self):
+        """objectPoints[c][p] / imagePoints[c][p]: (n,1,3)/(n,1,2) float32 or None."""
+        objs, imgs = [], []
+        for c in range(self.n_cams):
+            o, i, vp = self.obj[c].cpu().numpy(), self.img[c].cpu().numpy(), self.view_ptr[c]
+            lo = [None] * self.n_poses
+            li = [None] * self.n_poses
+            for k, p in enumerate(self.pose_idx[c]):
+                lo[p] = o[vp[k]:vp[k + 1]].reshape(-1, 1, 3).copy()
+                li[p] = i[vp[k]:vp[k + 1]].reshape(-1, 1, 2).copy()
+            objs.append(lo)
+            imgs.append(li)
+        return objs, imgs
+
+    def guess_matrices(self):
+        Ks, Ds = [], []
+        for g in self.intr_guess:
+            Ks.append(np.array([[g[0], 0, g[2]], [0, g[1], g[3]], [0, 0, 1.0]]))
+            Ds.append(np.array(g[4:], dtype=np.float64).reshape(-1, 1))
+        return Ks, Ds
+
+
+def make_rig(n_poses, n_cams=4, board=None, size=(2960, 1664), seed=4, noise=0.2, device="cpu",
+             yaw_deg=(0.0, 35.0, -35.0, 70.0), baseline=120.0, max_incidence_deg=70.0, margin=8.0):
+    """Fisheye rig: cameras fanned about the rig's Y axis, board poses sampled
+    in the frame of one camera (round robin) and kept in every camera whose
+    image holds all corners."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    dt = torch.float64
+    board = (board if board is not None else board_points(11, 8, 25.0)).to(device=device, dtype=dt)
+    nb = board.shape[0]
+    base = np.array(list(FISHEYE_TRUE_K) + list(FISHEYE_TRUE_D))
+    rel = np.array([[0, 0, 0, 0, 0, 0, 0, 0], [.02, .02, -.01, .015, .1, -.1, .1, -.1],
+                    [-.015, -.015, .012, -.02, -.1, .1, -.1, .1], [.01, .012, .02, .01, .05, .05, -.05, -.05]])
+    intr_true = np.stack([base * (1 + rel[c % 4]) for c in range(n_cams)])
+    guess = np.array(list(FISHEYE_GUESS_K) + list(FISHEYE_GUESS_D))
+    intr_guess = np.stack([guess for _ in range(n_cams)])
+    ext = torch.zeros(n_cams, 6, dtype=dt, device=device)
+    for c in range(1, n_cams):
+        yaw = math.radians(yaw_deg[c % len(yaw_deg)]) * (1 + c // len(yaw_deg))
+        ext[c, 1] = yaw
+        ext[c, 0] = 0.03 * c                                      # small pitch so no axis is special
+        ext[c, 3] = -baseline * c * math.copysign(1.0, yaw if yaw != 0 else 1.0)
+        ext[c, 4] = 5.0 * c
+        ext[c, 5] = 10.0 * c
+    Rc = _rot_from_rvec(ext[:, :3])
+    tc = ext[:, 3:]
+    # poses in the frame of camera (p mod n_cams), moved to the rig frame
+    per = (n_poses + n_cams - 1) // n_cams
+    poses = torch.empty(n_poses, 6, dtype=dt, device=device)
+    for c in range(n_cams):
+        idx = torch.arange(c, n_poses, n_cams, device=device)
+        if idx.numel() == 0:
+            continue
+        pc = sample_poses("fisheye", board, tuple(intr_true[c, :4]), tuple(intr_true[c, 4:]), size, per, gen,
+                          device=device, max_incidence_deg=max_incidence_deg, margin=margin)[:idx.numel()]
+        Rpc = _rot_from_rvec(pc[:, :3])
+        Rp = Rc[c].T @ Rpc
+        tp = (pc[:, 3:] - tc[c]) @ Rc[c]                        # R_c^T (t_pc - t_c)
+        poses[idx] = torch.cat([_rvec_from_rot(Rp), tp], dim=1)
+    Rp = _rot_from_rvec(poses[:, :3])
+    max_inc = math.radians(max_incidence_deg)
+    w, h = size
+    pose_idx, view_ptr, objs, imgs = [], [], [], []
+    for c in range(n_cams):
+        R = Rc[c] @ Rp
+        t = poses[:, 3:] @ Rc[c].T + tc[c]
+        px, depth, rad = project("fisheye", board.expand(n_poses, -1, -1), _rvec_from_rot(R), t,
+                                 tuple(intr_true[c, :4]), tuple(intr_true[c, 4:]))
+        ok = (depth > 50.0).all(dim=1) & (rad < max_inc).all(dim=1)
+        ok &= (px[..., 0] > margin).all(dim=1) & (px[..., 0] < w - margin).all(dim=1)
+        ok &= (px[..., 1] > margin).all(dim=1) & (px[..., 1] < h - margin).all(dim=1)
+        ok &= torch.isfinite(px).all(dim=2).all(dim=1)
+        sel = torch.nonzero(ok)[:, 0]
+        pxs = px[sel]
+        if noise > 0:
+            pxs = pxs + noise * torch.randn(pxs.shape, generator=gen, device=device, dtype=dt)
+        pose_idx.append(sel.cpu().numpy().astype(np.int64))
+        vp = np.arange(sel.numel() + 1, dtype=np.int64) * nb
+        view_ptr.append(vp)
+        objs.append(board.expand(sel.numel(), -1, -1).reshape(-1, 3).to(torch.float32))
+        imgs.append(pxs.reshape(-1, 2).to(torch.float32))
+    return RigProblem(model="fisheye", image_size=tuple(size), n_poses=n_poses, intr_true=intr_true,
+                      intr_guess=intr_guess, ext_true=ext.cpu().numpy(), poses_true=poses.cpu().numpy(),
+                      pose_idx=pose_idx, view_ptr=view_ptr, obj=objs, img=imgs,
+                      meta=dict(seed=seed, noise=noise, board=(int(nb),)))
+
+
 def config(name, device="cpu", n_views=None, noise=None, seed=None):
-    """BASELINE.json configs by name: C1, C2, C3, C5 (C4, the rig, is not
-    built in this round)."""
+    """BASELINE.json configs by name: C1, C2, C3, C5 return a :class:`Problem`,
+    C4 (``n_views`` = board poses) a :class:`RigProblem`."""
     name = name.upper()
     if name == "C1":
         return make_problem("pinhole", n_views or 20, board_points(9, 6, 25.0), (1920, 1080),
@@ -281,6 +396,9 @@ def config(name, device="cpu", n_views=None, noise=None, seed=None):
                             FISHEYE_TRUE_K, FISHEYE_TRUE_D, FISHEYE_GUESS_K, FISHEYE_GUESS_D,
                             seed if seed is not None else 3, 0.2 if noise is None else noise, device,
                             ragged=(13, 63), name="C3")
+    if name == "C4":
+        return make_rig(n_views or 10000, 4, seed=seed if seed is not None else 4,
+                        noise=0.2 if noise is None else noise, device=device)
     if name == "C5":
         return make_problem("fisheye", n_views or 1000000, board_points(11, 8, 25.0), (2960, 1664),
                             FISHEYE_TRUE_K, FISHEYE_TRUE_D, FISHEYE_GUESS_K, FISHEYE_GUESS_D,

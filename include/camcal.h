@@ -167,6 +167,42 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
                       double* g, double* glob, double* schur, double* scratch, void* stream,
                       float* ms_out_host);
 
+/* ---- Multi-camera rig (BASELINE.json config 4; no reference counterpart: the tool
+ * calibrates its cameras one after another, controller_internal_calibration.py:375-399).
+ * Residual proj_c(R_c (R_p X + t_p) + t_c) - obs; each camera is an ordinary packed
+ * view set whose per-slot pose is the composed transform.  slot_pose[s] = board-pose
+ * index of slot s (-1 padding); rig_pose [6][P]; ext [6] = (r_c, t_c) on the device. */
+
+/* composed pose (R_c R_p, R_c t_p + t_c) of every slot of one camera */
+int camcal_rig_compose(const camcal_tiles* tiles, const int32_t* slot_pose, const double* rig_pose,
+                       int64_t P, const double* ext, double* pose_out, void* stream);
+
+/* single-pass evaluation of one camera in the LOCAL tangent frame of the composed
+ * poses: glob = [U|b|cost] of that camera's intrinsics, V, W, g per slot */
+int camcal_rig_local_blocks(int model, const camcal_tiles* tiles, const double* intr,
+                            const double* pose, double* V, double* W, double* g, double* glob,
+                            double* scratch, void* stream);
+
+/* chain rule to the rig parameters for one camera: per board pose Vp [21][P],
+ * gp [6][P], Wp [(NI+6)*6][P] (rows: intrinsics then extrinsics; zero where the
+ * camera does not see the pose) and rec_ext = [U_ie (NI*6) | U_ee (21) | b_e (6)] */
+int camcal_rig_assemble(int model, const camcal_tiles* tiles, const int32_t* slot_pose,
+                        const double* rig_pose, int64_t P, const double* ext, const double* V,
+                        const double* W, const double* g, double* Vp, double* gp, double* Wp,
+                        double* rec_ext, double* scratch, void* stream);
+
+/* per board pose: V = sum_c Vp_c (diag*(1+lam)) = U^T U;  Y [6P][n_cams*(NI+6)] =
+ * U^-T Wp^T and z [6P] = U^-T g, so that C = Y^T Y and d = Y^T z (library GEMM).
+ * *_all arrays are the per-camera arrays of camcal_rig_assemble back to back. */
+int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp_all,
+                          const double* gp_all, const double* Wp_all, double lam, double* Y,
+                          double* z, void* stream);
+
+/* d_p = V'^-1 (g_p - Wp^T dG), pose_out = pose_in - d_p; norms as camcal_backsub */
+int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
+                       const double* Wp_all, double lam, const double* dG, const double* pose_in,
+                       double* pose_out, double* norms, double* scratch, void* stream);
+
 /* Peak probes for the roofline report: kind 0 = dependent-free FP64 FMA stream
  * (result TFLOP/s), kind 1 = streaming read of `bytes` from buf with 16-byte loads
  * (result GB/s), kind 2 = the same with 4-byte loads (PMC calibration of the point-load shape).
