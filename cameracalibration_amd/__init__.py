@@ -25,6 +25,10 @@ from .api import (  # noqa: F401
     CALIB_FIX_K4, CALIB_FIX_K5, CALIB_FIX_K6, CALIB_RATIONAL_MODEL, CALIB_THIN_PRISM_MODEL,
     CALIB_FIX_S1_S2_S3_S4, CALIB_TILTED_MODEL, CALIB_FIX_TAUX_TAUY, CALIB_FIX_TANGENT_DIST,
 )
+from .points import (  # noqa: F401
+    projectPoints, norm, checkRange, undistortPoints, solvePnP, solvePnP_batch, initUndistortRectifyMap,
+    Rodrigues, reproj_errors, NORM_L2, CV_16SC2, CV_32FC1, SOLVEPNP_ITERATIVE,
+)
 from . import fisheye  # noqa: F401
 from .rig import calibrate_rig  # noqa: F401
 

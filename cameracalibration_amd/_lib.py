@@ -50,6 +50,10 @@ _SIGNATURES = {
     "camcal_rig_assemble": (C.c_int, [_I, _TP, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_rig_pose_schur": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P]),
     "camcal_rig_backsub": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
+    "camcal_project_points": (C.c_int, [_I, C.c_int64, _P, _P, _P, _P, _P]),
+    "camcal_reproj_err": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P]),
+    "camcal_undistort_points": (C.c_int, [_I, C.c_int64, _P, _P, _P, _P, _P]),
+    "camcal_undistort_rectify_map": (C.c_int, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "camcal_peak_probe": (C.c_int, [_I, _P, C.c_int64, _I, _P, C.POINTER(C.c_double)]),
 }
 

@@ -84,7 +84,24 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def _gather_views(object_points, image_points):
+_test_backend = None
+
+
+def _set_test_backend(lib, device):
+    """Tests only: route every call of this package to the given library (the
+    CPU lane emulator of tests/hostemu) and device; ``None, None`` restores."""
+    global _test_backend
+    _test_backend = None if lib is None else (lib, torch.device(device))
+
+
+def _resolve(lib_override=None, device_override=None):
+    """(lib or None for the HIP build, device) of a call."""
+    if lib_override is None and device_override is None and _test_backend is not None:
+        return _test_backend
+    return lib_override, (device_override if device_override is not None else _device())
+
+
+def _gather_views(object_points, image_points, min_points=4):
     """cv2-style lists of (n_i,1,3)/(n_i,1,2) arrays -> CSR float32 arrays."""
     try:
         nv = len(object_points)
@@ -104,8 +121,8 @@ def _gather_views(object_points, image_points):
         i = i.reshape(-1, 2).astype(np.float32, copy=False)
         if o.shape[0] != i.shape[0]:
             raise error("number of object and image points must be equal in every view")
-        if o.shape[0] < 4:
-            raise error("every view needs at least 4 points")
+        if o.shape[0] < min_points:
+            raise error("every view needs at least %d points" % min_points)
         objs.append(o)
         imgs.append(i)
         counts.append(o.shape[0])
@@ -199,7 +216,7 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
         maxc = 1000
     if not ctype & TERM_CRITERIA_EPS:
         eps = DBL_EPSILON
-    dev = _device_override if _device_override is not None else _device()
+    _lib_override, dev = _resolve(_lib_override, _device_override)
     E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=_lib_override)
     E.set_intr(0, np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], dist]))
     # cvFindExtrinsicCameraParams2 per view: homography init + iterative refine
@@ -259,7 +276,7 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
         if flags & f:
             mask[4 + j] = False
             k[j] = 0.0
-    dev = _device_override if _device_override is not None else _device()
+    _lib_override, dev = _resolve(_lib_override, _device_override)
     E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=_lib_override)
     E.set_intr(0, np.concatenate([[Kin[0, 0], Kin[1, 1], Kin[0, 2], Kin[1, 2]], k]))
     # CalibrateExtrinsics: InitExtrinsics + ComputeExtrinsicRefine per view

@@ -15,6 +15,7 @@
 #include "../../include/camcal.h"
 #include "camcal_lane.h"
 #include "camcal_rig.h"
+#include "camcal_points.h"
 
 using namespace camcal;
 
@@ -559,6 +560,100 @@ inline int tiles_ok(const camcal_tiles* t) {
   if (!t->tile_off || !t->tile_nmax || !t->lane_n) return 0;
   return 1;
 }
+// ---------------------------------------------------------------------------
+// Point-level kernels (camcal_points.h)
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_project_points(int64_t n, const double* __restrict__ xyz,
+                                                        const double* __restrict__ pose6,
+                                                        const double* __restrict__ intr, double* __restrict__ uv) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p[6], R[9], I[MT<MODEL>::NI];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) p[c] = pose6[c];
+#pragma unroll
+  for (int c = 0; c < MT<MODEL>::NI; ++c) I[c] = intr[c];
+  rodrigues(p, R);
+  const double X[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+  double u, v;
+  project_point<MODEL>(X, R, p + 3, I, u, v);
+  uv[i * 2] = u;
+  uv[i * 2 + 1] = v;
+}
+
+template <int MODEL, bool PLANAR, bool F32>
+__global__ __launch_bounds__(TPB) void k_reproj_err(camcal_tiles tiles, const double* __restrict__ intr,
+                                                    const double* __restrict__ pose, double* __restrict__ err,
+                                                    double* __restrict__ scratch) {
+  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * WPB;
+  const int lane = threadIdx.x & 63;
+  double I[MT<MODEL>::NI];
+#pragma unroll
+  for (int c = 0; c < MT<MODEL>::NI; ++c) I[c] = intr[c];
+  double acc[2] = {0.0, 0.0};
+  for (int tile = wave; tile < tiles.n_tiles; tile += n_waves) {
+    const int64_t slot = (int64_t)tile * LANES + lane;
+    LaneTile tv;
+    tv.base = tiles.pts + tiles.tile_off[tile] + lane;
+    tv.n = tiles.lane_n[slot];
+    tv.nmax = tiles.tile_nmax[tile];
+    double p[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) p[c] = pose[c * tiles.n_slots + slot];
+    const double e = lane_reproj_err<MODEL, PLANAR, F32>(tv, I, p);
+    err[slot] = e;
+    acc[0] += e;
+    acc[1] += tv.n > 0 ? 1.0 : 0.0;
+  }
+  wave_reduce_store<2>(acc, scratch, wave);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_undistort_points(int64_t n, const double* __restrict__ uv,
+                                                          const double* __restrict__ intr,
+                                                          const double* __restrict__ M, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double I[MT<MODEL>::NI], Mm[9];
+#pragma unroll
+  for (int c = 0; c < MT<MODEL>::NI; ++c) I[c] = intr[c];
+  if (M) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Mm[c] = M[c];
+  }
+  double x, y;
+  undistort_point<MODEL>(uv[i * 2], uv[i * 2 + 1], I, M ? Mm : nullptr, x, y);
+  out[i * 2] = x;
+  out[i * 2 + 1] = y;
+}
+
+template <int MODEL, int MAP_TYPE>
+__global__ __launch_bounds__(TPB) void k_rectify_map(int width, int height, const double* __restrict__ intr,
+                                                     const double* __restrict__ iR, void* __restrict__ map1,
+                                                     void* __restrict__ map2) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)width * height) return;
+  const int i = (int)(idx / width), j = (int)(idx - (int64_t)i * width);
+  double I[MT<MODEL>::NI], Q[9];
+#pragma unroll
+  for (int c = 0; c < MT<MODEL>::NI; ++c) I[c] = intr[c];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Q[c] = iR[c];
+  double u, v;
+  const bool ok = rectify_map_px<MODEL>(i, j, Q, I, u, v);
+  if (MAP_TYPE == 0) {
+    ((float*)map1)[idx] = (float)u;
+    ((float*)map2)[idx] = (float)v;
+  } else {
+    short mx = -1, my = -1;
+    unsigned short fr = 0;
+    if (ok) encode_fixed_map(u, v, mx, my, fr);
+    ((short2*)map1)[idx] = make_short2(mx, my);
+    ((unsigned short*)map2)[idx] = fr;
+  }
+}
+
 inline int grid_tiles(const camcal_tiles* t) { return (t->n_tiles + WPB - 1) / WPB; }
 inline int grid_persistent(const camcal_tiles* t) {
   const int g = grid_tiles(t);
@@ -878,6 +973,73 @@ int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, c
   else hipLaunchKernelGGL(k_rig_backsub<14>, dim3((unsigned)nb), dim3(TPB), 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, dG, pose_in, pose_out, scratch);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_finalize, dim3(2), dim3(TPB), 0, s, scratch, (int)nb * WPB, norms);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_project_points(int model, int64_t n, const double* xyz, const double* pose6, const double* intr,
+                          double* uv, void* stream) {
+  if (n < 0 || (n > 0 && (!xyz || !uv)) || !pose6 || !intr) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  if (n == 0) return 0;
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_project_points<PINHOLE>, g, b, 0, s, n, xyz, pose6, intr, uv);
+  else hipLaunchKernelGGL(k_project_points<FISHEYE>, g, b, 0, s, n, xyz, pose6, intr, uv);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_reproj_err(int model, const camcal_tiles* tiles, const double* intr, const double* pose, int f32_round,
+                      double* err, double* sum_out, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !err || !sum_out || !scratch) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int gp = grid_persistent(tiles);
+  const dim3 gr(gp), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (f32_round) {
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_reproj_err<M, P, true>), gr, b, 0, s, *tiles, intr, pose, err, scratch)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
+  } else {
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_reproj_err<M, P, false>), gr, b, 0, s, *tiles, intr, pose, err, scratch)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
+  }
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_finalize, dim3(2), dim3(TPB), 0, s, scratch, gp * WPB, sum_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_undistort_points(int model, int64_t n, const double* uv, const double* intr, const double* M, double* out,
+                            void* stream) {
+  if (n < 0 || (n > 0 && (!uv || !out)) || !intr) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  if (n == 0) return 0;
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_undistort_points<PINHOLE>, g, b, 0, s, n, uv, intr, M, out);
+  else hipLaunchKernelGGL(k_undistort_points<FISHEYE>, g, b, 0, s, n, uv, intr, M, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_undistort_rectify_map(int model, int width, int height, const double* intr, const double* iR, int map_type,
+                                 void* map1, void* map2, void* stream) {
+  if (width <= 0 || height <= 0 || !intr || !iR || !map1 || !map2 || (map_type != 0 && map_type != 1))
+    return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int64_t n = (int64_t)width * height;
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (model == CAMCAL_PINHOLE) {
+    if (map_type == 0) hipLaunchKernelGGL((k_rectify_map<PINHOLE, 0>), g, b, 0, s, width, height, intr, iR, map1, map2);
+    else hipLaunchKernelGGL((k_rectify_map<PINHOLE, 1>), g, b, 0, s, width, height, intr, iR, map1, map2);
+  } else {
+    if (map_type == 0) hipLaunchKernelGGL((k_rectify_map<FISHEYE, 0>), g, b, 0, s, width, height, intr, iR, map1, map2);
+    else hipLaunchKernelGGL((k_rectify_map<FISHEYE, 1>), g, b, 0, s, width, height, intr, iR, map1, map2);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -252,6 +252,15 @@ class Engine:
                        self.W.data_ptr() if store_blocks else None, self.g.data_ptr(),
                        self.glob[0].data_ptr(), self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
 
+    def reproj_err(self, intr_idx, pose_idx, f32_round=True):
+        """Per-view ||proj - corners||_2 / n (caller's view order) and their mean."""
+        out = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._call("camcal_reproj_err", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), 1 if f32_round else 0, self.view_cost.data_ptr(),
+                   out.data_ptr(), self.scratch.data_ptr(), self._stream())
+        o = out.cpu().numpy()
+        return self.slots_to_views(self.view_cost), float(o[0] / max(o[1], 1.0))
+
     def time_stage(self, stage, reps, lam=0.0):
         """Average milliseconds per launch of one stage, HIP events on the
         current stream (0 evaluation A, 1 view_blocks, 2 schur from stored blocks,

@@ -1,6 +1,11 @@
 """``cv2.fisheye`` namespace stand-in: ``calibrate`` and its flag constants
-(reference: server/aruco/camera_calib.py:74-77)."""
+(reference: server/aruco/camera_calib.py:74-77), ``projectPoints`` (:97),
+``undistortPoints`` (:241) and ``initUndistortRectifyMap``
+(server/video/video_server.py:473)."""
 from .api import fisheye_calibrate as calibrate  # noqa: F401
+from .points import fisheye_projectPoints as projectPoints  # noqa: F401
+from .points import fisheye_undistortPoints as undistortPoints  # noqa: F401
+from .points import fisheye_initUndistortRectifyMap as initUndistortRectifyMap  # noqa: F401
 from .api import (  # noqa: F401
     FISHEYE_CALIB_USE_INTRINSIC_GUESS as CALIB_USE_INTRINSIC_GUESS,
     FISHEYE_CALIB_RECOMPUTE_EXTRINSIC as CALIB_RECOMPUTE_EXTRINSIC,

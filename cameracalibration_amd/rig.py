@@ -375,7 +375,7 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
     Returns (rms, Ks, Ds, Ts, rvecs, tvecs): Ts[c] = (rvec, tvec) of
     camera-from-rig (camera 0: zeros), rvecs/tvecs the board poses in the rig
     frame (tuples of (3,1) arrays; poses no camera sees keep (0,0,0 | 0,0,1))."""
-    from .api import _device
+    from .api import _resolve
     mdl = {"pinhole": _lib.PINHOLE, "fisheye": _lib.FISHEYE}[model]
     if cams is None:
         cams, n_poses = _gather_rig(objectPoints, imagePoints)
@@ -390,7 +390,7 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
         if K.shape != (3, 3) or D.size != nd:
             raise ValueError("cameraMatrix must be 3x3 and distCoeffs hold %d coefficients" % nd)
         intr0[c] = np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], D])
-    dev = _device_override if _device_override is not None else _device()
+    _lib_override, dev = _resolve(_lib_override, _device_override)
     R = RigEngine(mdl, cams, n_poses, dev, lib=_lib_override)
     comm = _comm or Comm()
     R.set_params(0, intr0, np.zeros((nC, 6)))

@@ -203,6 +203,36 @@ int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, c
                        const double* Wp_all, double lam, const double* dG, const double* pose_in,
                        double* pose_out, double* norms, double* scratch, void* stream);
 
+/* ---- Point-level operations either side of the solver ---- */
+
+/* cv2.projectPoints / cv2.fisheye.projectPoints for one pose (camera_calib.py:97,175;
+ * intrinsicCalib.py:143,235): xyz [n][3] -> uv [n][2], all double, all on the device;
+ * pose6 = (rvec, tvec). */
+int camcal_project_points(int model, int64_t n, const double* xyz, const double* pose6,
+                          const double* intr, double* uv, void* stream);
+
+/* The tool's acceptance number for every packed view at once: err[slot] =
+ * ||proj - corners||_2 / n  (camera_calib.py:96-104,174-181; intrinsicCalib.py:137-146,
+ * 229-238); sum_out = [sum of err over views, number of views] so that the caller's
+ * np.mean is sum_out[0] / sum_out[1].  f32_round != 0 rounds the projection to float32
+ * and subtracts in float32 as cv2 does for float32 corner arrays. */
+int camcal_reproj_err(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
+                      int f32_round, double* err, double* sum_out, double* scratch, void* stream);
+
+/* cv2.undistortPoints / cv2.fisheye.undistortPoints (camera_calib.py:241,252,261,281,292,
+ * 301; controller_internal_calibration.py:553,570): uv [n][2] pixels -> out [n][2];
+ * M = P[:, :3] * R row-major on the device, or NULL for normalised coordinates. */
+int camcal_undistort_points(int model, int64_t n, const double* uv, const double* intr,
+                            const double* M, double* out, void* stream);
+
+/* cv2.initUndistortRectifyMap / cv2.fisheye.initUndistortRectifyMap
+ * (video_server.py:473,497; intrinsicCalib.py:159,251): iR = (newK * R)^-1 row-major on
+ * the device; map_type 0: map1, map2 float32 [h][w] (CV_32FC1), 1: map1 int16 [h][w][2],
+ * map2 uint16 [h][w] (CV_16SC2 + CV_16UC1 fixed point, INTER_BITS 5). */
+int camcal_undistort_rectify_map(int model, int width, int height, const double* intr,
+                                 const double* iR, int map_type, void* map1, void* map2,
+                                 void* stream);
+
 /* Peak probes for the roofline report: kind 0 = dependent-free FP64 FMA stream
  * (result TFLOP/s), kind 1 = streaming read of `bytes` from buf with 16-byte loads
  * (result GB/s), kind 2 = the same with 4-byte loads (PMC calibration of the point-load shape).

@@ -153,6 +153,19 @@ def per_view_reproj_err(model, views, intr, poses):
     return out
 
 
+def per_view_reproj_err_f32(model, views_obj, views_img, intr, poses):
+    """The same number computed the way the tool's loop does with float32 corner
+    arrays: cv2.projectPoints returns float32 for float32 object points, and
+    cv2.norm subtracts in float32 and accumulates in double."""
+    out = np.empty(len(views_obj))
+    for k, (o, i) in enumerate(zip(views_obj, views_img)):
+        X = np.asarray(o).reshape(1, -1, 3).astype(np.float64)
+        (p,) = _project(model, X, poses[k:k + 1, :3], poses[k:k + 1, 3:], intr, False)
+        d = (p[0].astype(np.float32) - np.asarray(i, dtype=np.float32).reshape(-1, 2)).astype(np.float64)
+        out[k] = np.sqrt((d * d).sum()) / X.shape[1]
+    return out
+
+
 # --- small dense helpers -----------------------------------------------------
 def _svd_solve(A, b):
     """cv::solve(A, b, DECOMP_SVD): pseudo-inverse with OpenCV's threshold

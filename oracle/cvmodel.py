@@ -294,3 +294,62 @@ def undistort_fisheye(uv, K4, dist, alpha=0.0, max_iter=10, eps=1e-8):
     out = np.stack([px * scale, py * scale], axis=-1)
     out[~ok] = -1000000.0
     return out
+
+
+def undistort_points(model, uv, K4, dist, R=None, P=None):
+    """cv2.undistortPoints / cv2.fisheye.undistortPoints with the optional
+    rectification R and new camera matrix P applied afterwards (RR = P[:, :3] R;
+    reference call sites: camera_calib.py:241,252,261,281,292,301 and
+    controller_internal_calibration.py:553,570, which passes a camera matrix as R)."""
+    if model == "pinhole":
+        xy = undistort_pinhole(uv, K4, dist)
+        bad = np.zeros(xy.shape[:-1], dtype=bool)
+    else:
+        xy = undistort_fisheye(uv, K4, dist)
+        bad = xy[..., 0] == -1000000.0
+    if R is None and P is None:
+        return xy
+    RR = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    if P is not None:
+        RR = np.asarray(P, dtype=np.float64)[:, :3] @ RR
+    h = np.concatenate([xy, np.ones(xy.shape[:-1] + (1,))], axis=-1) @ RR.T
+    out = h[..., :2] / h[..., 2:3]
+    out[bad] = -1000000.0
+    return out
+
+
+def rectify_map(model, K4, dist, R, newK, size, fixed_point=False):
+    """cv2.initUndistortRectifyMap / cv2.fisheye.initUndistortRectifyMap
+    (video_server.py:473,497; intrinsicCalib.py:159,251): for every destination
+    pixel the source pixel; CV_32FC1 pair, or CV_16SC2 + CV_16UC1 fixed point
+    (INTER_BITS = 5, cvRound)."""
+    w, h = size
+    fx, fy, cx, cy = [float(v) for v in K4]
+    iR = np.linalg.inv(np.asarray(newK, dtype=np.float64)[:, :3] @ (np.eye(3) if R is None else np.asarray(R)))
+    j, i = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    _x = j * iR[0, 0] + i * iR[0, 1] + iR[0, 2]
+    _y = j * iR[1, 0] + i * iR[1, 1] + iR[1, 2]
+    _w = j * iR[2, 0] + i * iR[2, 1] + iR[2, 2]
+    x, y = _x / _w, _y / _w
+    d = np.asarray(dist, dtype=np.float64).ravel()
+    if model == "fisheye":
+        r = np.sqrt(x * x + y * y)
+        th = np.arctan(r)
+        t2 = th * th
+        thd = th * (1 + d[0] * t2 + d[1] * t2 ** 2 + d[2] * t2 ** 3 + d[3] * t2 ** 4)
+        sc = np.where(r == 0, 1.0, thd / np.where(r == 0, 1.0, r))
+        u, v = fx * x * sc + cx, fy * y * sc + cy
+    else:
+        k = np.zeros(5)
+        k[:d.size] = d[:5]
+        r2 = x * x + y * y
+        kr = 1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2
+        u = fx * (x * kr + k[2] * 2 * x * y + k[3] * (r2 + 2 * x * x)) + cx
+        v = fy * (y * kr + k[2] * (r2 + 2 * y * y) + k[3] * 2 * x * y) + cy
+    if not fixed_point:
+        return u.astype(np.float32), v.astype(np.float32)
+    iu = np.rint(u * 32).astype(np.int64)
+    iv = np.rint(v * 32).astype(np.int64)
+    m1 = np.stack([iu >> 5, iv >> 5], axis=-1).astype(np.int16)
+    m2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
+    return m1, m2

@@ -14,6 +14,7 @@
 #include "../../include/camcal.h"
 #include "../../cameracalibration_amd/csrc/camcal_lane.h"
 #include "../../cameracalibration_amd/csrc/camcal_rig.h"
+#include "../../cameracalibration_amd/csrc/camcal_points.h"
 
 using namespace camcal;
 
@@ -390,6 +391,66 @@ int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp, const
                        double lam, const double* dG, const double* pin, double* pout, double* norms, double*, void*) {
   if (model == 0) rig_backsub<15>(n_cams, P, Vp, gp, Wp, lam, dG, pin, pout, norms);
   else rig_backsub<14>(n_cams, P, Vp, gp, Wp, lam, dG, pin, pout, norms);
+  return 0;
+}
+int camcal_project_points(int model, int64_t n, const double* xyz, const double* pose6, const double* intr,
+                          double* uv, void*) {
+  double R[9];
+  rodrigues(pose6, R);
+  for (int64_t i = 0; i < n; ++i) {
+    if (model == 0) project_point<PINHOLE>(xyz + 3 * i, R, pose6 + 3, intr, uv[2 * i], uv[2 * i + 1]);
+    else project_point<FISHEYE>(xyz + 3 * i, R, pose6 + 3, intr, uv[2 * i], uv[2 * i + 1]);
+  }
+  return 0;
+}
+int camcal_reproj_err(int model, const camcal_tiles* t, const double* intr, const double* pose, int f32_round,
+                      double* err, double* sum_out, double*, void*) {
+  double s = 0, cnt = 0;
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int lane = 0; lane < LANES; ++lane) {
+      const int64_t slot = (int64_t)tile * LANES + lane;
+      const LaneTile tv = lane_tile(t, tile, lane);
+      double p[6], e;
+      load_pose(pose, t->n_slots, slot, p);
+      const bool pl = t->planar != 0, f = f32_round != 0;
+#define RE(M) (pl ? (f ? lane_reproj_err<M, true, true>(tv, intr, p) : lane_reproj_err<M, true, false>(tv, intr, p)) \
+                  : (f ? lane_reproj_err<M, false, true>(tv, intr, p) : lane_reproj_err<M, false, false>(tv, intr, p)))
+      e = model == 0 ? RE(PINHOLE) : RE(FISHEYE);
+#undef RE
+      err[slot] = e;
+      s += e;
+      cnt += tv.n > 0 ? 1.0 : 0.0;
+    }
+  sum_out[0] = s; sum_out[1] = cnt;
+  return 0;
+}
+int camcal_undistort_points(int model, int64_t n, const double* uv, const double* intr, const double* M, double* out,
+                            void*) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (model == 0) undistort_point<PINHOLE>(uv[2 * i], uv[2 * i + 1], intr, M, out[2 * i], out[2 * i + 1]);
+    else undistort_point<FISHEYE>(uv[2 * i], uv[2 * i + 1], intr, M, out[2 * i], out[2 * i + 1]);
+  }
+  return 0;
+}
+int camcal_undistort_rectify_map(int model, int width, int height, const double* intr, const double* iR, int map_type,
+                                 void* map1, void* map2, void*) {
+  for (int i = 0; i < height; ++i)
+    for (int j = 0; j < width; ++j) {
+      const int64_t idx = (int64_t)i * width + j;
+      double u, v;
+      const bool ok = model == 0 ? rectify_map_px<PINHOLE>(i, j, iR, intr, u, v) : rectify_map_px<FISHEYE>(i, j, iR, intr, u, v);
+      if (map_type == 0) {
+        ((float*)map1)[idx] = (float)u;
+        ((float*)map2)[idx] = (float)v;
+      } else {
+        short mx = -1, my = -1;
+        unsigned short fr = 0;
+        if (ok) encode_fixed_map(u, v, mx, my, fr);
+        ((short*)map1)[2 * idx] = mx;
+        ((short*)map1)[2 * idx + 1] = my;
+        ((unsigned short*)map2)[idx] = fr;
+      }
+    }
   return 0;
 }
 int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 0.0; return 0; }

@@ -1,0 +1,209 @@
+"""Shared bodies of the point-level parity tests (N1-N4): run with the CPU lane
+emulator in the CPU tier and with the HIP library in the GPU tier."""
+import numpy as np
+
+import cameracalibration_amd as cc
+from cameracalibration_amd import synth, wrappers
+from oracle import cvcalib as O
+from oracle import cvmodel as M
+
+FE = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+
+
+def Kmat(k4):
+    return np.array([[k4[0], 0, k4[2]], [0, k4[1], k4[3]], [0, 0, 1.0]])
+
+
+def case_project_points():
+    rng = np.random.default_rng(0)
+    X = np.concatenate([rng.uniform(-300, 300, (50, 2)), rng.uniform(-40, 40, (50, 1))], axis=1)
+    rvec, tvec = np.array([0.2, -0.3, 0.5]), np.array([20.0, -30.0, 900.0])
+    for model, K4, D, fn in (("pinhole", synth.PINHOLE_TRUE_K, synth.PINHOLE_TRUE_D, cc.projectPoints),
+                             ("fisheye", synth.FISHEYE_TRUE_K, synth.FISHEYE_TRUE_D, cc.fisheye.projectPoints)):
+        ref = (M.project_pinhole if model == "pinhole" else M.project_fisheye)(X, rvec, tvec, K4, D)
+        got, jac = fn(X.reshape(-1, 1, 3), rvec.reshape(3, 1), tvec.reshape(3, 1), Kmat(K4), np.array(D))
+        assert jac is None and got.shape == (50, 1, 2) and got.dtype == np.float64
+        assert np.abs(got.reshape(-1, 2) - ref).max() < 1e-9
+        got32, _ = fn(X.astype(np.float32).reshape(-1, 1, 3), rvec, tvec, Kmat(K4), np.array(D))
+        assert got32.dtype == np.float32
+        ref32 = (M.project_pinhole if model == "pinhole" else M.project_fisheye)(
+            X.astype(np.float32).astype(np.float64), rvec, tvec, K4, D)
+        assert np.abs(got32.reshape(-1, 2) - ref32).max() < 2e-4
+    # pinhole with 4 coefficients (the "normal" cameras of configs/fg/inter_cfg.json)
+    got, _ = cc.projectPoints(X.reshape(-1, 1, 3), rvec, tvec, Kmat(synth.PINHOLE_TRUE_K),
+                              np.array(synth.PINHOLE_TRUE_D[:4]))
+    ref = M.project_pinhole(X, rvec, tvec, synth.PINHOLE_TRUE_K, synth.PINHOLE_TRUE_D[:4])
+    assert np.abs(got.reshape(-1, 2) - ref).max() < 1e-9
+
+
+def case_reproj_errors():
+    for name, model in (("C1", "pinhole"), ("C3", "fisheye")):
+        P = synth.config(name, n_views=70)
+        objs, imgs = P.as_lists()
+        intr = P.intr_true() * (1 + 1e-4)
+        poses = P.poses_true.numpy()
+        rv, tv = [p[:3].reshape(3, 1) for p in poses], [p[3:].reshape(3, 1) for p in poses]
+        nd = 5 if model == "pinhole" else 4
+        err, mean = cc.reproj_errors(model, objs, imgs, rv, tv, Kmat(intr[:4]), intr[4:4 + nd])
+        ref = O.per_view_reproj_err_f32(model, objs, imgs, intr, poses)
+        assert np.abs(err - ref).max() < 1e-6 and abs(mean - ref.mean()) < 1e-7
+        err64, _ = cc.reproj_errors(model, objs, imgs, rv, tv, Kmat(intr[:4]), intr[4:4 + nd], f32_round=False)
+        ref64 = O.per_view_reproj_err(model, O.Views(objs, imgs), intr, poses)
+        assert np.abs(err64 - ref64).max() < 1e-11
+        # the reference's own loop, call by call
+        pp = cc.projectPoints if model == "pinhole" else cc.fisheye.projectPoints
+        for k in (0, 17, 69):
+            re, _ = pp(objs[k], rv[k], tv[k], Kmat(intr[:4]), intr[4:4 + nd])
+            e = cc.norm(re, imgs[k], cc.NORM_L2) / len(re)
+            assert abs(e - err[k]) < 1e-12 * max(1.0, e) + 1e-12
+
+
+def case_undistort_points():
+    rng = np.random.default_rng(1)
+    Rm = M.rodrigues(np.array([0.05, -0.1, 0.02]))[0]
+    for model, K4, D, fn, size in (("pinhole", synth.PINHOLE_TRUE_K, synth.PINHOLE_TRUE_D, cc.undistortPoints, (1920, 1080)),
+                                   ("fisheye", synth.FISHEYE_TRUE_K, synth.FISHEYE_TRUE_D, cc.fisheye.undistortPoints,
+                                    (2960, 1664))):
+        uv = np.stack([rng.uniform(0, size[0], 200), rng.uniform(0, size[1], 200)], axis=1)
+        K = Kmat(K4)
+        P2 = K.copy()
+        P2[0, 0] *= 0.6
+        P2[1, 1] *= 0.6
+        for R, Pm in ((None, None), (None, K), (None, P2), (Rm, None), (Rm, P2), (np.multiply(K, [[0.6, 1, 1], [1, 0.6, 1], [1, 1, 1]]), None)):
+            ref = M.undistort_points(model, uv, K4, D, R, Pm)
+            src = uv.reshape(-1, 1, 2)
+            got = fn(src, K, np.array(D), R=R, P=Pm)
+            assert got.shape == (200, 1, 2) and got.dtype == np.float64
+            sc = max(1.0, np.abs(ref[ref > -1e5]).max())
+            assert np.abs(got.reshape(-1, 2) - ref).max() < 1e-9 * sc
+        # in-place float32 form used by calib_ex_* (dst is the source array)
+        src32 = uv.astype(np.float32).reshape(-1, 1, 2)
+        ref = M.undistort_points(model, src32.reshape(-1, 2).astype(np.float64), K4, D, None, K)
+        out = fn(src32, K, np.array(D), src32, P=K)
+        assert out is src32 and np.allclose(src32.reshape(-1, 2), ref, rtol=3e-7, atol=5e-4)
+    # a fisheye pixel far outside the model's range does not converge -> (-1e6, -1e6)
+    bad = cc.fisheye.undistortPoints(np.array([[[1e5, 1e5]]]), Kmat(synth.FISHEYE_TRUE_K),
+                                     np.array([0.5, -3.0, 0.0, 0.0]))
+    ref = M.undistort_fisheye(np.array([[1e5, 1e5]]), synth.FISHEYE_TRUE_K, [0.5, -3.0, 0.0, 0.0])
+    assert np.allclose(bad.reshape(-1, 2), ref)
+
+
+def case_solve_pnp():
+    P = synth.config("C1", n_views=12, seed=9)
+    objs, imgs = P.as_lists()
+    K, D = Kmat(P.K_true), np.array(P.D_true)
+    intr = P.intr_true()
+    ok, rv, tv = cc.solvePnP_batch(objs, imgs, K, D)
+    assert ok.all()
+    for k in range(12):
+        ref = O.find_extrinsics_pinhole(objs[k].reshape(-1, 3).astype(np.float64),
+                                        imgs[k].reshape(-1, 2).astype(np.float64), intr)
+        assert np.abs(rv[k] - ref[:3]).max() < 1e-6 and np.abs(tv[k] - ref[3:]).max() < 1e-4
+    ret, r1, t1 = cc.solvePnP(objs[3], imgs[3], K, D)
+    assert ret is True and r1.shape == (3, 1) and t1.shape == (3, 1)
+    assert np.allclose(r1.ravel(), rv[3]) and np.allclose(t1.ravel(), tv[3])
+    # the calib_ex flow: undistort to an ideal pinhole, then PnP with zero distortion
+    flat = cc.undistortPoints(imgs[3].copy(), K, D, P=K)
+    ret, r2, t2 = cc.solvePnP(objs[3], flat, K, np.zeros_like(D))
+    assert np.abs(r2.ravel() - P.poses_true[3, :3].numpy()).max() < 5e-3
+
+
+def case_rectify_maps():
+    for model, K4, D, fn, size in (("pinhole", synth.PINHOLE_TRUE_K, synth.PINHOLE_TRUE_D, cc.initUndistortRectifyMap, (240, 135)),
+                                   ("fisheye", synth.FISHEYE_TRUE_K, synth.FISHEYE_TRUE_D,
+                                    cc.fisheye.initUndistortRectifyMap, (185, 104))):
+        K = Kmat(K4)
+        newK = K.copy()
+        newK[0, 0] *= 0.5
+        newK[1, 1] *= 0.5
+        newK[0, 2], newK[1, 2] = size[0] / 2, size[1] / 2
+        for R in (np.eye(3), M.rodrigues(np.array([0.02, 0.01, -0.03]))[0]):
+            m1, m2 = fn(K, np.array(D), R, newK, size, cc.CV_32FC1)
+            r1, r2 = M.rectify_map(model, K4, D, R, newK, size)
+            assert m1.shape == (size[1], size[0]) and m1.dtype == np.float32
+            assert np.abs(m1 - r1).max() < 2e-3 and np.abs(m2 - r2).max() < 2e-3
+            f1, f2 = fn(K, np.array(D), R, newK, size, cc.CV_16SC2)
+            g1, g2 = M.rectify_map(model, K4, D, R, newK, size, fixed_point=True)
+            assert f1.shape == (size[1], size[0], 2) and f1.dtype == np.int16 and f2.dtype == np.uint16
+            # fixed point: identical except where u*32 sits within rounding noise of a half
+            full = f1.astype(np.int64) * 32 + np.stack([f2 & 31, f2 >> 5], axis=-1)
+            gfull = g1.astype(np.int64) * 32 + np.stack([g2 & 31, g2 >> 5], axis=-1)
+            assert np.abs(full - gfull).max() <= 1 and (full != gfull).mean() < 1e-3
+
+
+def case_wrappers():
+    # Camera_Cali.calib_in_fisheye / _normal against the oracle run through the same steps
+    for kind, cfg, nv in (("fisheye", "C2", 24), ("pinhole", "C1", 12)):
+        P = synth.config(cfg, n_views=nv)
+        objs, imgs = P.as_lists()
+        cal = wrappers.Camera_Cali()
+        K_before = cal.init_camera_mat.copy()
+        data = cal.calib_in(objs, imgs, P.image_size, "fisheye" if kind == "fisheye" else "normal")
+        o_tr, o_te, i_tr, i_te = wrappers.split_points(objs, imgs, test_size=0.1, random_state=42)
+        assert all(len(t) == int(len(o) * 0.1) for t, o in zip(o_te, objs))
+        if kind == "fisheye":
+            ref = O.fisheye_calibrate(o_tr, i_tr, P.image_size, np.array(wrappers.FISHEYE_INIT_K),
+                                      np.array(wrappers.FISHEYE_INIT_D), flags=FE, criteria=(3, 1000, 1e-6))
+            assert data.camera_mat is cal.init_camera_mat          # the aliasing the callers live with
+            assert not np.allclose(cal.init_camera_mat, K_before)
+        else:
+            ref = O.calibrate_camera(o_tr, i_tr, P.image_size, np.array(wrappers.NORMAL_INIT_K),
+                                     np.array(wrappers.NORMAL_INIT_D), flags=1, criteria=(3, 1000, 1e-6))
+            assert data.camera_mat is not cal.init_camera_mat_normal
+            assert np.array_equal(cal.init_camera_mat_normal, np.array(wrappers.NORMAL_INIT_K))
+        assert abs(data.ok - ref[0]) < 1e-6 and np.allclose(data.camera_mat, ref[1], rtol=1e-6)
+        intr = np.concatenate([[ref[1][0, 0], ref[1][1, 1], ref[1][0, 2], ref[1][1, 2]], ref[2].ravel()])
+        poses = np.hstack([ref[3], ref[4]])
+        e = O.per_view_reproj_err_f32(kind, o_te, i_te, intr, poses).mean()
+        assert abs(data.reproj_err - e) < 1e-5
+        assert len(data.rvecs) == nv and data.rvecs[0].shape == (3, 1)
+    few = wrappers.Camera_Cali().calib_in(objs[:3], imgs[:3], P.image_size, "normal")
+    assert few.camera_mat is None and few.ok is False
+    # the incremental classes: init (100 iterations) then refine (10) on a grown list
+    P = synth.config("C2", n_views=16)
+    objs, imgs = P.as_lists()
+    fe = wrappers.Fisheye(frame_width=296, frame_height=166)
+    fe.board = list(objs[:10])
+    fe.update(list(imgs[:10]), P.image_size)
+    assert fe.inited and fe.data.type == "FISHEYE" and fe.data.ok and len(fe.data.reproj_err) == 10
+    ref = O.fisheye_calibrate(objs[:10], imgs[:10], P.image_size, np.array(wrappers.FISHEYE_INIT_K),
+                              np.array(wrappers.FISHEYE_INIT_D), flags=FE, criteria=(3, 100, 1e-6))
+    assert np.allclose(fe.data.camera_mat, ref[1], rtol=1e-6)
+    assert fe.data.map1.shape == (166, 296, 2) and fe.data.map2.dtype == np.uint16
+    K1 = fe.data.camera_mat.copy()
+    fe.board = list(objs)
+    fe.update(list(imgs), P.image_size)
+    ref2 = O.fisheye_calibrate(objs, imgs, P.image_size, K1, ref[2], flags=FE, criteria=(3, 10, 1e-6))
+    assert np.allclose(fe.data.camera_mat, ref2[1], rtol=1e-6) and len(fe.data.reproj_err) == 16
+    intr = np.concatenate([[ref2[1][0, 0], ref2[1][1, 1], ref2[1][0, 2], ref2[1][1, 2]], ref2[2].ravel()])
+    e = O.per_view_reproj_err_f32("fisheye", objs, imgs, intr, np.hstack([ref2[3], ref2[4]]))
+    assert np.abs(np.array(fe.data.reproj_err) - e).max() < 1e-5
+    P = synth.config("C1", n_views=10)
+    objs, imgs = P.as_lists()
+    nm = wrappers.Normal(frame_width=192, frame_height=108)
+    nm.board = list(objs)
+    nm.update(list(imgs), P.image_size)
+    assert nm.data.type == "NORMAL" and nm.data.ok and nm.data.map1.shape == (108, 192, 2)
+    # calib_ex: pose of one shared board, fisheye and pinhole flows
+    for kind, cfg in (("fisheye", "C2"), ("normal", "C1")):
+        P = synth.config(cfg, n_views=4, noise=0.0)
+        objs, imgs = P.as_lists()
+        K, D = Kmat(P.K_true), np.array(P.D_true).reshape(-1, 1)
+        ids = list(range(len(objs[1])))
+        ret, rv, tv, pd, pdp = wrappers.Camera_Cali().calib_ex(objs[1].copy(), imgs[1].copy(), ids, K, D,
+                                                             check_mode=True, camera_type=kind)
+        assert ret and np.abs(rv.ravel() - P.poses_true[1, :3].numpy()).max() < 1e-3
+        assert np.abs(tv.ravel() - P.poses_true[1, 3:].numpy()).max() < 0.5
+        assert len(pd) == len(ids) and len(pdp) == len(ids)
+    # inter_cfg.json wire format
+    entry = wrappers.create_internal((2960, 1664), Kmat(synth.FISHEYE_TRUE_K), np.array(synth.FISHEYE_TRUE_D).reshape(4, 1))
+    assert len(entry) == 15 and entry[:2] == [2960, 1664] and entry[4] == synth.FISHEYE_TRUE_K[2]
+    size, K, D = wrappers.parse_internal(entry)
+    assert size == (2960, 1664) and np.array_equal(K, Kmat(synth.FISHEYE_TRUE_K)) and D.shape == (4,)
+    import json
+    txt = wrappers.dumps_internal({"left_calib": entry})
+    assert json.loads(txt)["left_calib"] == entry and txt.startswith('{\n    "left_calib": [\n        2960, \n')
+
+
+ALL = [case_project_points, case_reproj_errors, case_undistort_points, case_solve_pnp, case_rectify_maps,
+       case_wrappers]

@@ -92,6 +92,15 @@ def test_rig_solve_matches_oracle_gpu(dev):
     assert np.allclose(e2, ext, atol=1e-7) and np.allclose(p2, poses, atol=1e-6)
 
 
+def test_rig_golden_gpu(dev):
+    from tests.test_rig_cpu import load_rig_golden, check_rig_golden
+    z, cams, Ks, Ds = load_rig_golden()
+    info = {}
+    out = rig.calibrate_rig(None, None, tuple(z["image_size"]), Ks, Ds, criteria=(3, 40, 1e-9), cams=cams,
+                            n_poses=int(z["n_poses"]), _device_override=dev, _info=info)
+    check_rig_golden(z, out, info)
+
+
 def test_single_camera_rig_is_calibrate_camera_gpu(dev):
     import cameracalibration_amd as cc
     P = synth.config("C1")

@@ -1,0 +1,30 @@
+"""SURVEY.md 8f rows N1-N4 and the wrapper mirrors on the CPU tier: the host
+logic of points.py / wrappers.py over the CPU lane emulator against the oracle."""
+import pytest
+import torch
+
+from cameracalibration_amd import api
+from tests import points_cases
+
+
+@pytest.fixture()
+def emulated(emu):
+    api._set_test_backend(emu, torch.device("cpu"))
+    yield
+    api._set_test_backend(None, None)
+
+
+@pytest.mark.parametrize("case", points_cases.ALL, ids=[c.__name__ for c in points_cases.ALL])
+def test_points_on_emulator(case, emulated):
+    case()
+
+
+def test_sample_inter_cfg_layout():
+    """The layout of the reference's sample configs/fg/inter_cfg.json (first entry
+    restated here: 2 + 9 + 4 numbers, K row-major with zeros and the trailing 1)."""
+    from cameracalibration_amd import wrappers
+    left = [2960, 1664, 1055.0521257175044, 0.0, 1476.6648858909566, 0.0, 1054.6401168165328, 887.5653467911538,
+            0.0, 0.0, 1.0, -0.04777389954125019, 0.0931613753239662, -0.2708946929491217, 0.2967182854093386]
+    size, K, D = wrappers.parse_internal(left)
+    assert size == (2960, 1664) and K[0, 1] == 0 and K[2, 2] == 1 and D.size == 4
+    assert wrappers.create_internal(size, K, D.reshape(4, 1)) == left

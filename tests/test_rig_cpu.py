@@ -172,6 +172,32 @@ def test_single_camera_fisheye_rig_reaches_fisheye_minimum(emu):
     assert np.allclose(out[1][0], ref[1], rtol=1e-6) and np.allclose(out[2][0], ref[2], rtol=1e-3, atol=1e-7)
 
 
+def load_rig_golden():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "rig", "rig_fisheye_3x12.npz"), allow_pickle=False)
+    cams = [dict(pose_idx=z[f"pose_idx{c}"], view_ptr=z[f"view_ptr{c}"], obj=z[f"obj{c}"], img=z[f"img{c}"])
+            for c in range(3)]
+    Ks = [np.array([[g[0], 0, g[2]], [0, g[1], g[3]], [0, 0, 1.0]]) for g in z["intr_guess"]]
+    Ds = [g[4:].reshape(-1, 1) for g in z["intr_guess"]]
+    return z, cams, Ks, Ds
+
+
+def check_rig_golden(z, out, info):
+    assert info["iters"] == int(z["iters"])
+    assert abs(out[0] - float(z["rms"])) < 1e-8
+    i2, e2, p2 = info["engine"].get_params(0)
+    assert np.allclose(i2[:, :4], z["intr"][:, :4], rtol=1e-8)
+    assert np.allclose(i2[:, 4:], z["intr"][:, 4:], rtol=1e-6, atol=1e-9)
+    assert np.allclose(e2, z["ext"], atol=1e-7) and np.allclose(p2, z["poses"], atol=1e-6)
+
+
+def test_rig_golden_on_emulator(emu):
+    z, cams, Ks, Ds = load_rig_golden()
+    info = {}
+    out = rig.calibrate_rig(None, None, tuple(z["image_size"]), Ks, Ds, criteria=(3, 40, 1e-9), cams=cams,
+                            n_poses=int(z["n_poses"]), _lib_override=emu, _device_override=CPU, _info=info)
+    check_rig_golden(z, out, info)
+
+
 def test_rig_rejects_bad_input(emu):
     R = small_rig(6, 2)
     objs, imgs = R.as_lists()
