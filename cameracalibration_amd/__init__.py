@@ -27,7 +27,7 @@ from .api import (  # noqa: F401
 )
 from .points import (  # noqa: F401
     projectPoints, norm, checkRange, undistortPoints, solvePnP, solvePnP_batch, initUndistortRectifyMap,
-    Rodrigues, reproj_errors, NORM_L2, CV_16SC2, CV_32FC1, SOLVEPNP_ITERATIVE,
+    Rodrigues, reproj_errors, remap, INTER_LINEAR, BORDER_CONSTANT, NORM_L2, CV_16SC2, CV_32FC1, SOLVEPNP_ITERATIVE,
 )
 from . import fisheye  # noqa: F401
 from .rig import calibrate_rig  # noqa: F401

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "camcal_reproj_err": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P]),
     "camcal_undistort_points": (C.c_int, [_I, C.c_int64, _P, _P, _P, _P, _P]),
     "camcal_undistort_rectify_map": (C.c_int, [_I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "camcal_remap_u8": (C.c_int, [_P, _I, _I, C.c_int64, _I, _P, _P, _I, _I, _I, _P, C.c_int64, _I, _P]),
     "camcal_peak_probe": (C.c_int, [_I, _P, C.c_int64, _I, _P, C.POINTER(C.c_double)]),
 }
 

@@ -654,6 +654,27 @@ __global__ __launch_bounds__(TPB) void k_rectify_map(int width, int height, cons
   }
 }
 
+template <int MAP_TYPE>
+__global__ __launch_bounds__(TPB) void k_remap_u8(const unsigned char* __restrict__ src, int sw, int sh,
+                                                  long long sstride, int cn, const void* __restrict__ map1,
+                                                  const void* __restrict__ map2, int dw, int dh,
+                                                  unsigned char* __restrict__ dst, long long dstride,
+                                                  unsigned char cval) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)dw * dh) return;
+  const int i = (int)(idx / dw), j = (int)(idx - (int64_t)i * dw);
+  int ix, iy, fx, fy;
+  if (MAP_TYPE == 0) {
+    const int sx = remap_fixed_coord(((const float*)map1)[idx]), sy = remap_fixed_coord(((const float*)map2)[idx]);
+    ix = sat_short(sx >> 5); iy = sat_short(sy >> 5); fx = sx & 31; fy = sy & 31;
+  } else {
+    const short2 m = ((const short2*)map1)[idx];
+    const int a = ((const unsigned short*)map2)[idx] & 1023;
+    ix = m.x; iy = m.y; fx = a & 31; fy = a >> 5;
+  }
+  remap_pixel_u8(src, sw, sh, sstride, cn, ix, iy, fx, fy, cval, dst + (long long)i * dstride + (long long)j * cn);
+}
+
 inline int grid_tiles(const camcal_tiles* t) { return (t->n_tiles + WPB - 1) / WPB; }
 inline int grid_persistent(const camcal_tiles* t) {
   const int g = grid_tiles(t);
@@ -1040,6 +1061,22 @@ int camcal_undistort_rectify_map(int model, int width, int height, const double*
     if (map_type == 0) hipLaunchKernelGGL((k_rectify_map<FISHEYE, 0>), g, b, 0, s, width, height, intr, iR, map1, map2);
     else hipLaunchKernelGGL((k_rectify_map<FISHEYE, 1>), g, b, 0, s, width, height, intr, iR, map1, map2);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_remap_u8(const unsigned char* src, int src_w, int src_h, int64_t src_stride, int channels,
+                    const void* map1, const void* map2, int map_type, int dst_w, int dst_h, unsigned char* dst,
+                    int64_t dst_stride, int border_value, void* stream) {
+  if (!src || !dst || !map1 || !map2 || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || channels <= 0 ||
+      channels > 4 || src_stride < (int64_t)src_w * channels || dst_stride < (int64_t)dst_w * channels ||
+      (map_type != 0 && map_type != 1) || border_value < 0 || border_value > 255)
+    return CAMCAL_E_BADARG;
+  const int64_t n = (int64_t)dst_w * dst_h;
+  const dim3 g((unsigned)((n + TPB - 1) / TPB)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (map_type == 0) hipLaunchKernelGGL(k_remap_u8<0>, g, b, 0, s, src, src_w, src_h, (long long)src_stride, channels, map1, map2, dst_w, dst_h, dst, (long long)dst_stride, (unsigned char)border_value);
+  else hipLaunchKernelGGL(k_remap_u8<1>, g, b, 0, s, src, src_w, src_h, (long long)src_stride, channels, map1, map2, dst_w, dst_h, dst, (long long)dst_stride, (unsigned char)border_value);
   HIP_TRY(hipGetLastError());
   return 0;
 }

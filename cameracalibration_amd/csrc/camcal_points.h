@@ -152,4 +152,33 @@ CC_HD void encode_fixed_map(double u, double v, short& mx, short& my, unsigned s
   frac = (unsigned short)((iv & 31) * 32 + (iu & 31));
 }
 
+// cv2.remap, INTER_LINEAR, BORDER_CONSTANT, 8-bit pixels (video_server.py:504;
+// intrinsicCalib.py:369): source position in 1/32 pixel fixed point (sx, sy =
+// cvRound(map * 32) for float maps, or map1 * 32 + the fractions of map2), the four
+// neighbours weighted with (32 - fx)(32 - fy) * 32 ... (exact products of cv2's
+// 15-bit weight table), rounded by (sum + 2^14) >> 15.
+CC_HD int remap_fixed_coord(float m) {
+  const double x = (double)m * 32.0;
+  if (!(x > -2147483648.0)) return -2147483647 - 1;
+  if (x >= 2147483647.0) return 2147483647;
+  return (int)nearbyint(x);
+}
+CC_HD int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+CC_HD void remap_pixel_u8(const unsigned char* src, int sw, int sh, long long sstride, int cn, int ix, int iy,
+                          int fx, int fy, unsigned char cval, unsigned char* dst) {
+  const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32,
+            w11 = fx * fy * 32;
+  const bool x0 = ix >= 0 && ix < sw, x1 = ix + 1 >= 0 && ix + 1 < sw;
+  const bool y0 = iy >= 0 && iy < sh, y1 = iy + 1 >= 0 && iy + 1 < sh;
+  const unsigned char* r0 = src + (long long)iy * sstride + (long long)ix * cn;
+  const unsigned char* r1 = r0 + sstride;
+  for (int c = 0; c < cn; ++c) {
+    const int p00 = (x0 && y0) ? r0[c] : cval, p01 = (x1 && y0) ? r0[cn + c] : cval;
+    const int p10 = (x0 && y1) ? r1[c] : cval, p11 = (x1 && y1) ? r1[cn + c] : cval;
+    const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+    dst[c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
+
 }  // namespace camcal

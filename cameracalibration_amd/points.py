@@ -28,6 +28,8 @@ from .api import _gather_views, _resolve, error
 from .engine import Engine
 
 NORM_L2 = 4
+INTER_LINEAR = 1
+BORDER_CONSTANT = 0
 CV_16SC2 = 11
 CV_32FC1 = 5
 SOLVEPNP_ITERATIVE = 0
@@ -271,6 +273,37 @@ def initUndistortRectifyMap(cameraMatrix, distCoeffs, R, newCameraMatrix, size, 
 def fisheye_initUndistortRectifyMap(K, D, R, P, size, m1type, *, _lib_override=None, _device_override=None):
     """``cv2.fisheye.initUndistortRectifyMap`` -> (map1, map2)."""
     return _rectify_map(_lib.FISHEYE, K, D, R, P, size, m1type, _lib_override, _device_override)
+
+
+def remap(src, map1, map2, interpolation=INTER_LINEAR, dst=None, borderMode=BORDER_CONSTANT, borderValue=0, *,
+          _lib_override=None, _device_override=None):
+    """``cv2.remap`` for 8-bit images, INTER_LINEAR, BORDER_CONSTANT, with the maps of
+    :func:`initUndistortRectifyMap` (float32 pair or CV_16SC2 + CV_16UC1)."""
+    lib, dev = _ctx(_lib_override, _device_override)
+    if interpolation != INTER_LINEAR or borderMode != BORDER_CONSTANT:
+        raise error("only INTER_LINEAR with BORDER_CONSTANT is provided")
+    img = np.asarray(src)
+    if img.dtype != np.uint8 or img.ndim not in (2, 3):
+        raise error("only 8-bit images of 1..4 channels are provided")
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    m1, m2 = np.asarray(map1), np.asarray(map2)
+    if m1.dtype == np.float32 and m1.ndim == 2 and m2.dtype == np.float32 and m2.shape == m1.shape:
+        mt = 0
+        t1, t2 = torch.from_numpy(np.ascontiguousarray(m1)).to(dev), torch.from_numpy(np.ascontiguousarray(m2)).to(dev)
+    elif m1.dtype == np.int16 and m1.ndim == 3 and m1.shape[2] == 2 and m2.dtype == np.uint16 \
+            and m2.shape == m1.shape[:2]:
+        mt = 1
+        t1 = torch.from_numpy(np.ascontiguousarray(m1)).to(dev)
+        t2 = torch.from_numpy(np.ascontiguousarray(m2).view(np.int16)).to(dev)
+    else:
+        raise error("maps must be a float32 pair or CV_16SC2 + CV_16UC1")
+    bv = int(borderValue[0] if np.ndim(borderValue) else borderValue)
+    dh, dw = m1.shape[:2]
+    t_src = torch.from_numpy(np.ascontiguousarray(img)).to(dev)
+    t_dst = torch.empty((dh, dw) + ((cn,) if img.ndim == 3 else ()), dtype=torch.uint8, device=dev)
+    _call(lib, dev, "camcal_remap_u8", t_src.data_ptr(), img.shape[1], img.shape[0], img.shape[1] * cn, cn,
+          t1.data_ptr(), t2.data_ptr(), mt, dw, dh, t_dst.data_ptr(), dw * cn, bv, _stream(dev))
+    return t_dst.cpu().numpy()
 
 
 # --- host-side scalar helper ---------------------------------------------------------------

@@ -233,6 +233,14 @@ int camcal_undistort_rectify_map(int model, int width, int height, const double*
                                  const double* iR, int map_type, void* map1, void* map2,
                                  void* stream);
 
+/* cv2.remap(src, map1, map2, INTER_LINEAR) with BORDER_CONSTANT for 8-bit images of 1..4
+ * channels (video_server.py:504; intrinsicCalib.py:369; ex_Calib.py:204,210): maps as
+ * written by camcal_undistort_rectify_map (map_type 0 float32 pair, 1 fixed point);
+ * strides in bytes; arithmetic is cv2's 1/32-pixel fixed point with 15-bit weights. */
+int camcal_remap_u8(const unsigned char* src, int src_w, int src_h, int64_t src_stride, int channels,
+                    const void* map1, const void* map2, int map_type, int dst_w, int dst_h,
+                    unsigned char* dst, int64_t dst_stride, int border_value, void* stream);
+
 /* Peak probes for the roofline report: kind 0 = dependent-free FP64 FMA stream
  * (result TFLOP/s), kind 1 = streaming read of `bytes` from buf with 16-byte loads
  * (result GB/s), kind 2 = the same with 4-byte loads (PMC calibration of the point-load shape).

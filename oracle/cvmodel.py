@@ -353,3 +353,35 @@ def rectify_map(model, K4, dist, R, newK, size, fixed_point=False):
     m1 = np.stack([iu >> 5, iv >> 5], axis=-1).astype(np.int16)
     m2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
     return m1, m2
+
+
+def remap_bilinear_u8(src, map1, map2, border_value=0):
+    """cv2.remap(src, map1, map2, INTER_LINEAR, borderMode=BORDER_CONSTANT) for uint8
+    images (video_server.py:504): 1/32-pixel fixed-point source position, the four
+    neighbours weighted with cv2's 15-bit bilinear table -- whose entries
+    (32-fx)(32-fy)*32 ... are exact, so the table's sum correction never acts --
+    and rounded by (sum + 2^14) >> 15; neighbours outside the image read the
+    border value."""
+    src = np.asarray(src)
+    img = src if src.ndim == 3 else src[..., None]
+    sh, sw, cn = img.shape
+    m1, m2 = np.asarray(map1), np.asarray(map2)
+    if m1.dtype == np.float32:
+        sx = np.rint(m1.astype(np.float64) * 32).astype(np.int64)
+        sy = np.rint(m2.astype(np.float64) * 32).astype(np.int64)
+        ix, iy = np.clip(sx >> 5, -32768, 32767), np.clip(sy >> 5, -32768, 32767)
+        fx, fy = sx & 31, sy & 31
+    else:
+        ix, iy = m1[..., 0].astype(np.int64), m1[..., 1].astype(np.int64)
+        a = m2.astype(np.int64) & 1023
+        fx, fy = a & 31, a >> 5
+    w = [(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32]
+    acc = np.zeros(ix.shape + (cn,), dtype=np.int64)
+    for (dy, dx), wk in zip(((0, 0), (0, 1), (1, 0), (1, 1)), w):
+        x, y = ix + dx, iy + dy
+        ok = (x >= 0) & (x < sw) & (y >= 0) & (y < sh)
+        px = img[np.clip(y, 0, sh - 1), np.clip(x, 0, sw - 1)].astype(np.int64)
+        px = np.where(ok[..., None], px, border_value)
+        acc += px * wk[..., None]
+    out = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+    return out if src.ndim == 3 else out[..., 0]

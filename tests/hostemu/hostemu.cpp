@@ -453,5 +453,23 @@ int camcal_undistort_rectify_map(int model, int width, int height, const double*
     }
   return 0;
 }
+int camcal_remap_u8(const unsigned char* src, int sw, int sh, int64_t sstride, int cn, const void* map1,
+                    const void* map2, int map_type, int dw, int dh, unsigned char* dst, int64_t dstride, int cval,
+                    void*) {
+  for (int i = 0; i < dh; ++i)
+    for (int j = 0; j < dw; ++j) {
+      const int64_t idx = (int64_t)i * dw + j;
+      int ix, iy, fx, fy;
+      if (map_type == 0) {
+        const int sx = remap_fixed_coord(((const float*)map1)[idx]), sy = remap_fixed_coord(((const float*)map2)[idx]);
+        ix = sat_short(sx >> 5); iy = sat_short(sy >> 5); fx = sx & 31; fy = sy & 31;
+      } else {
+        const int a = ((const unsigned short*)map2)[idx] & 1023;
+        ix = ((const short*)map1)[2 * idx]; iy = ((const short*)map1)[2 * idx + 1]; fx = a & 31; fy = a >> 5;
+      }
+      remap_pixel_u8(src, sw, sh, sstride, cn, ix, iy, fx, fy, (unsigned char)cval, dst + i * dstride + (int64_t)j * cn);
+    }
+  return 0;
+}
 int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 0.0; return 0; }
 }  // extern "C"

@@ -207,3 +207,89 @@ def case_wrappers():
 
 ALL = [case_project_points, case_reproj_errors, case_undistort_points, case_solve_pnp, case_rectify_maps,
        case_wrappers]
+
+
+def case_nonplanar_blocks():
+    """Object points with Z != 0 (the kernels' general path; the reference's boards
+    are planar so its callers never reach it): every evaluation form against the oracle."""
+    import torch
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    rng = np.random.default_rng(5)
+    for name, model, mid in (("C1", "pinhole", 0), ("C3", "fisheye", 1)):
+        P = synth.config(name, n_views=70)
+        obj = P.obj.numpy().copy()
+        obj[:, 2] = rng.uniform(-30, 30, obj.shape[0]).astype(np.float32)
+        vp = P.view_ptr
+        objs = [obj[vp[k]:vp[k + 1]].reshape(-1, 1, 3) for k in range(P.n_views)]
+        imgs = P.as_lists()[1]
+        views = O.Views(objs, imgs)
+        g, poses = P.intr_guess(), P.poses_true.numpy()
+        E = Engine(mid, vp, obj, P.img, dev, lib=lib)
+        assert E.tiles.planar == 0
+        E.set_intr(0, g)
+        E.set_poses(0, poses)
+        blk = O.normal_blocks(model, views, g, poses)
+        NI, nu = E.NI, E.NI * (E.NI + 1) // 2
+        i6 = np.triu_indices(6)
+
+        def rel(a, b):
+            return np.abs(np.asarray(a) - b).max() / np.abs(b).max()
+
+        for fused in (False, True):
+            E.normal_eq(0, 0, 1e-3, store_blocks=True, fused=fused)
+            G = E.glob[0].cpu().numpy()
+            U = np.zeros((NI, NI))
+            U[np.triu_indices(NI)] = G[:nu]
+            U = U + U.T - np.diag(np.diag(U))
+            assert rel(U, blk["U"]) < 1e-11 and rel(G[nu:nu + NI], blk["b"]) < 1e-10
+            assert abs(G[-1] / blk["cost"] - 1) < 1e-12
+            assert rel(E.slots_to_views(E.V.T), blk["V"][:, i6[0], i6[1]]) < 1e-11
+            assert rel(E.slots_to_views(E.W.T).reshape(-1, NI, 6), blk["W"]) < 1e-11
+            assert rel(E.slots_to_views(E.g.T), blk["g"]) < 1e-10
+        # projectPoints takes any Z
+        pp = cc.projectPoints if model == "pinhole" else cc.fisheye.projectPoints
+        nd = 5 if model == "pinhole" else 4
+        got, _ = pp(objs[3].astype(np.float64), poses[3, :3], poses[3, 3:], Kmat(g[:4]), g[4:4 + nd])
+        ref = (M.project_pinhole if model == "pinhole" else M.project_fisheye)(
+            objs[3].reshape(-1, 3).astype(np.float64), poses[3, :3], poses[3, 3:], g[:4], g[4:4 + nd])
+        assert np.abs(got.reshape(-1, 2) - ref).max() < 1e-9
+    # the solver API itself rejects non-planar targets (no planar-free pose initialiser)
+    try:
+        cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1)
+    except cc.error:
+        pass
+    else:
+        raise AssertionError("non-planar target accepted")
+
+
+ALL.append(case_nonplanar_blocks)
+
+
+def case_remap():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (104, 185, 3), dtype=np.uint8)
+    K = Kmat((100.0, 101.0, 92.0, 51.0))
+    D = np.array(synth.FISHEYE_TRUE_D)
+    newK = K.copy()
+    newK[0, 0] *= 0.5
+    newK[1, 1] *= 0.5
+    for size in ((185, 104), (370, 208)):                      # the reference doubles the fisheye output size
+        newK[0, 2], newK[1, 2] = size[0] / 2, size[1] / 2
+        for mtype in (cc.CV_32FC1, cc.CV_16SC2):
+            m1, m2 = cc.fisheye.initUndistortRectifyMap(K, D, np.eye(3), newK, size, mtype)
+            out = cc.remap(img, m1, m2, cc.INTER_LINEAR)
+            ref = M.remap_bilinear_u8(img, m1, m2)
+            assert out.shape == (size[1], size[0], 3) and out.dtype == np.uint8
+            assert np.array_equal(out, ref)                    # byte work: bit-exact
+            assert (ref == 0).all(axis=2).any() and (ref != 0).any()    # border and interior both exercised
+    gray = img[..., 0].copy()
+    m1, m2 = cc.initUndistortRectifyMap(K, np.array(synth.PINHOLE_TRUE_D), None, K, (185, 104), cc.CV_32FC1)
+    assert np.array_equal(cc.remap(gray, m1, m2, cc.INTER_LINEAR, borderValue=7), M.remap_bilinear_u8(gray, m1, m2, 7))
+    # identity map reproduces the image
+    jj, ii = np.meshgrid(np.arange(185, dtype=np.float32), np.arange(104, dtype=np.float32))
+    assert np.array_equal(cc.remap(img, jj, ii, cc.INTER_LINEAR), img)
+
+
+ALL.append(case_remap)
