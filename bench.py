@@ -66,6 +66,66 @@ def cpu_baseline(seconds_target=12.0):
         return {"value": None, "unit": "corner-obs/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
 
 
+def solve_times(dev):
+    """Wall-clock of whole solves through the drop-in API (SURVEY.md 8d asks for it
+    next to the evaluation rate): median of 3 after one warm-up, host lists in,
+    results out, so H2D, launches and every host round trip are inside."""
+    import cameracalibration_amd as cc
+    from cameracalibration_amd import rig
+    out = {}
+    fe = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+    crit = (3, 1000, 1e-6)
+
+    def med(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            info = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3, info
+
+    try:
+        P = synth.config("C1")
+        o, i = P.as_lists()
+
+        def c1():
+            info = {}
+            cc.calibrateCamera(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1, criteria=crit,
+                               _info=info)
+            return info
+        ms, info = med(c1)
+        out["C1_pinhole_20x54"] = {"ms": ms, "iterations": info["iters"]}
+        P2 = synth.config("C2")
+        o2, i2 = P2.as_lists()
+
+        def c2():
+            info = {}
+            cc.fisheye.calibrate(o2, i2, P2.image_size, P2.K_guess.copy(), P2.D_guess.copy(), flags=fe,
+                                 criteria=crit, _info=info)
+            return info
+        ms, info = med(c2)
+        out["C2_fisheye_500x88"] = {"ms": ms, "iterations": info["iters"]}
+        R = synth.config("C4", device=dev)
+        cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c])
+                for c in range(R.n_cams)]
+        Ks, Ds = R.guess_matrices()
+
+        def c4():
+            info = {}
+            rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-9), cams=cams,
+                              n_poses=R.n_poses, _info=info)
+            return info
+        ms, info = med(c4)
+        out["C4_rig_4x10000_poses"] = {"ms": ms, "iterations": info["iters"], "observations": R.n_obs,
+                                        "note": "points already on the device"}
+    except Exception as exc:      # reported, never required
+        out["error"] = str(exc)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +133,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--views", type=int, default=1_000_000, help="views per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solves", action="store_true", help="skip the whole-solve wall-clock extras")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,6 +243,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_solves:
+            del E
+            torch.cuda.empty_cache()
+            out["solve_wall_clock"] = solve_times(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -24,6 +24,8 @@ PINHOLE_GUESS_D = (-0.404256259818931, 0.21922420928359876, -0.00016181802429342
                    -7.126641144546051e-05, -0.06924570764420157)
 FISHEYE_TRUE_K = (1066.58, 1066.31, 1478.65, 791.19)
 FISHEYE_TRUE_D = (-0.02334, 0.007086, -0.005574, 0.000994)
+FISHEYE2_TRUE_K = (1100.0336809276707, 1059.556842631112, 1500.1849532258357, 867.406824905331)   # left_calib
+FISHEYE2_TRUE_D = (-0.021524158595833925, 0.00484506003924255, -0.003996810007141137, 0.0006446938071167349)
 FISHEYE_GUESS_K = (1062.267560, 1062.212564, 1501.057278, 867.887492)
 FISHEYE_GUESS_D = (-0.018123981144576858, -0.0026101267970621823, 0.0006215782316954739,
                    -0.00030905667520437564)
@@ -320,10 +322,13 @@ def make_rig(n_poses, n_cams=4, board=None, size=(2960, 1664), seed=4, noise=0.2
     dt = torch.float64
     board = (board if board is not None else board_points(11, 8, 25.0)).to(device=device, dtype=dt)
     nb = board.shape[0]
-    base = np.array(list(FISHEYE_TRUE_K) + list(FISHEYE_TRUE_D))
-    rel = np.array([[0, 0, 0, 0, 0, 0, 0, 0], [.02, .02, -.01, .015, .1, -.1, .1, -.1],
-                    [-.015, -.015, .012, -.02, -.1, .1, -.1, .1], [.01, .012, .02, .01, .05, .05, -.05, -.05]])
-    intr_true = np.stack([base * (1 + rel[c % 4]) for c in range(n_cams)])
+    # truths: the two fisheye entries of configs/internal/external_cfg.json (left_calib, right_calib)
+    # and +-2 % perturbations of them
+    left = np.array(list(FISHEYE2_TRUE_K) + list(FISHEYE2_TRUE_D))
+    right = np.array(list(FISHEYE_TRUE_K) + list(FISHEYE_TRUE_D))
+    pert = np.array([.02, .02, -.01, .015, .02, -.02, .02, -.02])
+    truths = [left, right, left * (1 + pert), right * (1 - pert)]
+    intr_true = np.stack([truths[c % 4] for c in range(n_cams)])
     guess = np.array(list(FISHEYE_GUESS_K) + list(FISHEYE_GUESS_D))
     intr_guess = np.stack([guess for _ in range(n_cams)])
     ext = torch.zeros(n_cams, 6, dtype=dt, device=device)

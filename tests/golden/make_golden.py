@@ -58,18 +58,19 @@ def main():
 
 def make_rig():
     """Config C4 at oracle size: 3 fisheye cameras x 12 board poses, dense
-    joint CvLevMarq (oracle/rig.py)."""
+    joint CvLevMarq (oracle/rig.py).  eps 1e-7: further iterations only move at
+    rounding level, where accept / reject decisions are not reproducible."""
     from oracle import rig as OR
     R = synth.make_rig(12, 3, board=synth.board_points(6, 5, 40.0), seed=21)
     objs, imgs = R.as_lists()
-    rms, intr, ext, poses, info = OR.rig_calibrate("fisheye", objs, imgs, R.intr_guess, max_iter=40, eps=1e-9)
+    rms, intr, ext, poses, info = OR.rig_calibrate("fisheye", objs, imgs, R.intr_guess, max_iter=40, eps=1e-7)
     os.makedirs(os.path.join(HERE, "rig"), exist_ok=True)
     np.savez_compressed(
         os.path.join(HERE, "rig", "rig_fisheye_3x12.npz"), image_size=np.array(R.image_size), n_poses=R.n_poses,
         **{f"pose_idx{c}": R.pose_idx[c] for c in range(3)}, **{f"view_ptr{c}": R.view_ptr[c] for c in range(3)},
         **{f"obj{c}": R.obj[c].numpy() for c in range(3)}, **{f"img{c}": R.img[c].numpy() for c in range(3)},
         intr_guess=R.intr_guess, intr_true=R.intr_true, ext_true=R.ext_true, poses_true=R.poses_true,
-        criteria=np.array([3, 40, 1e-9]), rms=rms, intr=intr, ext=ext, poses=poses, iters=info["iters"])
+        criteria=np.array([3, 40, 1e-7]), rms=rms, intr=intr, ext=ext, poses=poses, iters=info["iters"])
     print("rig_fisheye_3x12.npz rms", rms, "iters", info["iters"])
 
 
