@@ -115,7 +115,7 @@ def solve_times(dev):
 
         def c4():
             info = {}
-            rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-9), cams=cams,
+            rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-7), cams=cams,
                               n_poses=R.n_poses, _info=info)
             return info
         ms, info = med(c4)

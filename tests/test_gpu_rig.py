@@ -125,7 +125,7 @@ def test_config4_full_size_recovers_truth(dev):
     info = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-9), cams=cams,
+    out = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-7), cams=cams,
                             n_poses=R.n_poses, _device_override=dev, _info=info)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
@@ -153,7 +153,7 @@ def test_config4_full_size_recovers_truth(dev):
     K2 = [k.copy() for k in out[1]]
     D2 = [d.copy() for d in out[2]]
     info2 = {}
-    out2 = rig.calibrate_rig(None, None, R.image_size, K2, D2, criteria=(3, 30, 1e-9), cams=cams,
+    out2 = rig.calibrate_rig(None, None, R.image_size, K2, D2, criteria=(3, 30, 1e-7), cams=cams,
                              n_poses=R.n_poses, _device_override=dev, _info=info2, _init=(ext, poses))
-    assert info2["iters"] <= 2 and abs(out2[0] - out[0]) < 1e-9
+    assert info2["iters"] <= 2 and abs(out2[0] - out[0]) < 1e-8
     assert np.allclose(np.stack(out2[1]), np.stack(out[1]), rtol=1e-8)

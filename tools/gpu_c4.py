@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""C4 rig solve with its LM log (development tool)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cameracalibration_amd import synth, rig
+dev = torch.device("cuda:0")
+R = synth.config("C4", device=dev)
+cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c]) for c in range(4)]
+Ks, Ds = R.guess_matrices()
+info = {}
+t0 = time.perf_counter()
+out = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 40, 1e-7), cams=cams, n_poses=R.n_poses, _info=info)
+torch.cuda.synchronize()
+print("time", time.perf_counter() - t0, "rms", out[0])
+for l in info["log"]:
+    print(l)
+E = info["engine"]
+intr, ext, poses = E.get_params(0)
+d = np.abs(poses - R.poses_true).max(axis=1)
+print("worst poses", np.argsort(-d)[:5], np.sort(-d)[:5])
