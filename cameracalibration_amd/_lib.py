@@ -49,6 +49,7 @@ _SIGNATURES = {
     "camcal_rig_local_blocks": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_rig_assemble": (C.c_int, [_I, _TP, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_rig_pose_schur": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P]),
+    "camcal_rig_solve_reduced": (C.c_int, [_I, _I, _P, C.c_char_p, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_rig_backsub": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
     "camcal_project_points": (C.c_int, [_I, C.c_int64, _P, _P, _P, _P, _P]),
     "camcal_reproj_err": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P]),

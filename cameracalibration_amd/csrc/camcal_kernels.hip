@@ -675,6 +675,32 @@ __global__ __launch_bounds__(TPB) void k_remap_u8(const unsigned char* __restric
   remap_pixel_u8(src, sw, sh, sstride, cn, ix, iy, fx, fy, cval, dst + (long long)i * dstride + (long long)j * cn);
 }
 
+// Reduced solve of the rig on one wavefront (camcal_rig.h: rig_solve_*).
+__global__ __launch_bounds__(64) void k_rig_solve_reduced(int NI, int n_cams, const double* __restrict__ rec,
+                                                          unsigned long long mask, double lam,
+                                                          const double* __restrict__ intr_in,
+                                                          const double* __restrict__ ext_in,
+                                                          double* __restrict__ intr_out, double* __restrict__ ext_out,
+                                                          double* __restrict__ dG, double* __restrict__ stats) {
+  __shared__ RigSolveWs w;
+  const int lane = threadIdx.x, n = n_cams * (NI + 6);
+  rig_solve_build(lane, 64, NI, n_cams, rec, mask, lam, w);
+  __syncthreads();
+  rig_solve_scale(lane, 64, n, w);
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    rig_solve_chol_col(lane, 64, n, k, w);
+    __syncthreads();
+    rig_solve_chol_diag(lane, n, k, w);
+    rig_solve_chol_update(lane, 64, n, k, w);
+    __syncthreads();
+  }
+  if (lane == 0) {
+    rig_solve_substitute(n, w);
+    rig_solve_finish(NI, n_cams, mask, w, intr_in, ext_in, intr_out, ext_out, dG, stats);
+  }
+}
+
 inline int grid_tiles(const camcal_tiles* t) { return (t->n_tiles + WPB - 1) / WPB; }
 inline int grid_persistent(const camcal_tiles* t) {
   const int g = grid_tiles(t);
@@ -1077,6 +1103,23 @@ int camcal_remap_u8(const unsigned char* src, int src_w, int src_h, int64_t src_
   hipStream_t s = (hipStream_t)stream;
   if (map_type == 0) hipLaunchKernelGGL(k_remap_u8<0>, g, b, 0, s, src, src_w, src_h, (long long)src_stride, channels, map1, map2, dst_w, dst_h, dst, (long long)dst_stride, (unsigned char)border_value);
   else hipLaunchKernelGGL(k_remap_u8<1>, g, b, 0, s, src, src_w, src_h, (long long)src_stride, channels, map1, map2, dst_w, dst_h, dst, (long long)dst_stride, (unsigned char)border_value);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uint8_t* mask_host, double lam,
+                             const double* intr_in, const double* ext_in, double* intr_out, double* ext_out,
+                             double* dG, double* stats, void* stream) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  if (n_cams <= 0 || n_cams * (ni + 6) > RIG_MAXN || !rec || !mask_host || !intr_in || !ext_in || !intr_out ||
+      !ext_out || !dG || !stats)
+    return CAMCAL_E_BADARG;
+  unsigned long long mask = 0;
+  for (int i = 0; i < n_cams * (ni + 6); ++i)
+    if (mask_host[i]) mask |= 1ull << i;
+  hipLaunchKernelGGL(k_rig_solve_reduced, dim3(1), dim3(64), 0, (hipStream_t)stream, ni, n_cams, rec, mask, lam,
+                     intr_in, ext_in, intr_out, ext_out, dG, stats);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -166,4 +166,120 @@ CC_HD bool rig_pose_factor(int n_cams, const double* Vp_all, const double* gp_al
   return chol6(U);
 }
 
+// ---------------------------------------------------------------------------
+// Reduced system over the rig's n = n_cams * G globals (G = NI + 6, n <= 64):
+//   M = blockdiag_c [[U_ii U_ie], [U_ie^T U_ee]] (diag * (1 + lam))  -  C,   rhs = [b_i ; b_e] - d
+// from the record  rec = [ per camera: glob (NV = [U|b|cost]) | rext (NI*6 + 21 + 6) ] [ C (n x n) | d (n) ],
+// fixed parameters (mask bit clear) replaced by identity rows, Jacobi scaling,
+// Cholesky, solve.  Written as phases over a worker index (`lane` of `nl`) so
+// that the kernel runs one wavefront with a barrier between phases and the CPU
+// emulator loops the workers; element (i, j) sees the same operations in the
+// same order either way.  A (n x RIG_LD) and the vectors live in LDS / host memory.
+constexpr int RIG_MAXN = 64;
+constexpr int RIG_LD = RIG_MAXN + 1;
+
+struct RigSolveWs {
+  double A[RIG_MAXN * RIG_LD];
+  double rhs[RIG_MAXN], sc[RIG_MAXN], x[RIG_MAXN];
+  int ok;
+};
+
+CC_HD void rig_solve_build(int lane, int nl, int NI, int n_cams, const double* rec, unsigned long long mask,
+                           double lam, RigSolveWs& w) {
+  const int G = NI + 6, n = n_cams * G;
+  const int NU = NI * (NI + 1) / 2, NV = NU + NI + 1, NX = NI * 6 + 27;
+  const double* Cm = rec + (long long)n_cams * (NV + NX);
+  const double* d = Cm + (long long)n * n;
+  for (int i = lane; i < n; i += nl) {
+    const int c = i / G, a = i - c * G;
+    const double* glob = rec + (long long)c * (NV + NX);
+    const double* rx = glob + NV;
+    const bool fi = (mask >> i) & 1ull;
+    for (int j = 0; j < n; ++j) {
+      const int cj = j / G, b = j - cj * G;
+      const bool fj = (mask >> j) & 1ull;
+      double v = 0.0;
+      if (!fi || !fj) {
+        v = (i == j) ? 1.0 : 0.0;
+      } else {
+        if (c == cj) {
+          const int lo = a < b ? a : b, hi = a < b ? b : a;
+          if (hi < NI) v = glob[tri(NI, lo, hi)];
+          else if (lo < NI) v = rx[lo * 6 + (hi - NI)];
+          else v = rx[NI * 6 + tri(6, lo - NI, hi - NI)];
+          if (i == j) v *= 1.0 + lam;
+        }
+        v -= Cm[(long long)i * n + j];
+      }
+      w.A[i * RIG_LD + j] = v;
+    }
+    double r = 0.0;
+    if (fi) r = (a < NI ? glob[NU + a] : rx[NI * 6 + 21 + (a - NI)]) - d[i];
+    w.rhs[i] = r;
+    const double dii = w.A[i * RIG_LD + i];
+    w.sc[i] = dii > 0.0 ? 1.0 / sqrt(dii) : 1.0;
+  }
+  if (lane == 0) w.ok = 1;
+}
+CC_HD void rig_solve_scale(int lane, int nl, int n, RigSolveWs& w) {
+  for (int i = lane; i < n; i += nl) {
+    for (int j = 0; j < n; ++j) w.A[i * RIG_LD + j] *= w.sc[i] * w.sc[j];
+    w.rhs[i] *= w.sc[i];
+  }
+}
+// Cholesky step k, part 1: pivot and column k of L (lower triangle, in place)
+CC_HD void rig_solve_chol_col(int lane, int nl, int n, int k, RigSolveWs& w) {
+  const double p = w.A[k * RIG_LD + k];
+  const bool good = p > 0.0;
+  const double inv = good ? 1.0 / sqrt(p) : 0.0;
+  for (int i = k + 1 + lane; i < n; i += nl) w.A[i * RIG_LD + k] *= inv;
+  if (lane == 0 && !good) w.ok = 0;
+}
+CC_HD void rig_solve_chol_diag(int lane, int n, int k, RigSolveWs& w) {
+  if (lane == 0) {
+    const double p = w.A[k * RIG_LD + k];
+    w.A[k * RIG_LD + k] = p > 0.0 ? sqrt(p) : 1.0;
+  }
+}
+// part 2: trailing update, worker per column j > k
+CC_HD void rig_solve_chol_update(int lane, int nl, int n, int k, RigSolveWs& w) {
+  for (int j = k + 1 + lane; j < n; j += nl) {
+    const double ljk = w.A[j * RIG_LD + k];
+    for (int i = j; i < n; ++i) w.A[i * RIG_LD + j] = fma(-w.A[i * RIG_LD + k], ljk, w.A[i * RIG_LD + j]);
+  }
+}
+// triangular solves are short (n <= 64): one worker
+CC_HD void rig_solve_substitute(int n, RigSolveWs& w) {
+  for (int i = 0; i < n; ++i) {
+    double s = w.rhs[i];
+    for (int j = 0; j < i; ++j) s = fma(-w.A[i * RIG_LD + j], w.x[j], s);
+    w.x[i] = s / w.A[i * RIG_LD + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = w.x[i];
+    for (int j = i + 1; j < n; ++j) s = fma(-w.A[j * RIG_LD + i], w.x[j], s);
+    w.x[i] = s / w.A[i * RIG_LD + i];
+  }
+}
+// parameter update: out = in - dG; stats = [||dG||^2, ||globals_in||^2]; a failed
+// factorisation gives NaN so that the LM driver rejects the step
+CC_HD void rig_solve_finish(int NI, int n_cams, unsigned long long mask, RigSolveWs& w, const double* intr_in,
+                            const double* ext_in, double* intr_out, double* ext_out, double* dG, double* stats) {
+  const int G = NI + 6, n = n_cams * G;
+  double s0 = 0.0, s1 = 0.0;
+  const double bad = w.ok ? 0.0 : (0.0 / 0.0);
+  for (int i = 0; i < n; ++i) {
+    const int c = i / G, a = i - c * G;
+    const double dx = ((mask >> i) & 1ull) ? w.x[i] * w.sc[i] + bad : 0.0;
+    dG[i] = dx;
+    const double prev = a < NI ? intr_in[c * 16 + a] : ext_in[c * 6 + (a - NI)];
+    if (a < NI) intr_out[c * 16 + a] = prev - dx;
+    else ext_out[c * 6 + (a - NI)] = prev - dx;
+    s0 += dx * dx;
+    s1 += prev * prev;
+  }
+  stats[0] = s0;
+  stats[1] = s1;
+}
+
 }  // namespace camcal

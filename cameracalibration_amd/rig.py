@@ -19,9 +19,9 @@ same single-pass kernel as the single-camera solvers (local tangent frame).  A
 lane-per-view kernel applies the point-independent 6x6 chain rule to the rig
 parameters, a lane-per-pose kernel eliminates the pose blocks
 (``camcal_rig_*`` in include/camcal.h).  The reduced system over the
-n_cams*(NI+6) globals is formed with one library GEMM (Y^T Y) and solved with
-torch.linalg on the device; the host only sequences stages and reads back the
-cost and step norms of each trial.
+n_cams*(NI+6) <= 64 globals is formed with one library GEMM (Y^T Y) and
+solved by a one-wavefront Cholesky kernel; the host only sequences stages and
+reads back the cost and step norms of each trial.
 
 Multi-GPU: board poses are sharded across ranks (all cameras' views of a pose
 stay together); one all-reduce of the record [per-camera blocks | C | d] per
@@ -68,6 +68,8 @@ class RigEngine:
         self.NI = self.E[0].NI
         self.G = self.NI + 6
         self.nG = self.n_cams * self.G
+        if self.nG > 64:
+            raise ValueError("at most 64 global parameters (4 cameras) are supported by the reduced solve")
         self.NV = self.E[0].glob_len
         self.NX = self.NI * 6 + 27
         self.n_obs = sum(e.n_obs for e in self.E)
@@ -102,6 +104,7 @@ class RigEngine:
         self.z = torch.zeros(6 * P, **f64)
         self.dG = torch.zeros(self.nG, **f64)
         self.norms = torch.zeros(2, **f64)
+        self.gstats = torch.zeros(2, **f64)
         self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model, 1)), **f64)
         self._tri_i = torch.from_numpy(_tri_index(self.NI)).to(dev)
         self._tri_6 = torch.from_numpy(_tri_index(6)).to(dev)
@@ -186,19 +189,14 @@ class RigEngine:
         return M - Cm, rhs - d
 
     def solve(self, b, lam, free, out):
-        """dG = M^-1 rhs on the free globals; parameters[out] = parameters[b] - dG.
-        Returns (||dG||^2, ||globals||^2) as a 2-vector on the device."""
-        M, rhs = self.reduced_system(b, lam)
-        idx = free
-        sol = torch.linalg.solve(M[idx][:, idx], rhs[idx])
-        self.dG.zero_()
-        self.dG[idx] = sol
-        d = self.dG.view(self.n_cams, self.G)
-        self.intr[out].copy_(self.intr[b])
-        self.intr[out][:, :self.NI] -= d[:, :self.NI]
-        self.ext[out].copy_(self.ext[b] - d[:, self.NI:])
-        prev = torch.cat([self.intr[b][:, :self.NI].reshape(-1), self.ext[b].reshape(-1)])
-        return torch.stack([(self.dG * self.dG).sum(), (prev * prev).sum()])
+        """dG = M^-1 rhs on the free globals (``free``: boolean mask over the
+        n_cams*(NI+6) globals); parameters[out] = parameters[b] - dG.  Returns
+        (||dG||^2, ||globals||^2) as a 2-vector on the device."""
+        m = bytes(bytearray(int(bool(x)) for x in free))
+        self._call("camcal_rig_solve_reduced", self.model, self.n_cams, self.rec[b].data_ptr(), m, float(lam),
+                   self.intr[b].data_ptr(), self.ext[b].data_ptr(), self.intr[out].data_ptr(),
+                   self.ext[out].data_ptr(), self.dG.data_ptr(), self.gstats.data_ptr(), self._stream())
+        return self.gstats
 
     def backsub(self, b, lam, out):
         self._call("camcal_rig_backsub", self.model, self.n_cams, self.P, self.Vp[b].data_ptr(),
@@ -288,7 +286,7 @@ def lm_rig(R, free, max_iter, eps, comm=None, log=None):
     comm = comm or Comm(enabled=False)
     max_iter = int(min(max(max_iter, 1), 1000))
     eps = max(float(eps), DBL_EPSILON)
-    free = torch.as_tensor(np.nonzero(np.asarray(free, dtype=bool))[0], device=R.device)
+    free = np.asarray(free, dtype=bool)
     lam_lg10 = -3
     cur, tri = 0, 1
     R.evaluate(cur)

@@ -198,6 +198,15 @@ int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp_all
                           const double* gp_all, const double* Wp_all, double lam, double* Y,
                           double* z, void* stream);
 
+/* reduced solve over the n_cams*(NI+6) <= 64 globals from rec = [per camera: glob | rec_ext]
+ * [C | d] (C = Y^T Y, d = Y^T z): diag damped by (1+lam), parameters with mask_host[i] == 0
+ * held, Jacobi-scaled Cholesky on one wavefront; intr_out [n_cams][16] / ext_out [n_cams][6]
+ * = in - dG; stats = [||dG||^2, ||globals_in||^2]; NaN step if the matrix is not positive */
+int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uint8_t* mask_host,
+                             double lam, const double* intr_in, const double* ext_in,
+                             double* intr_out, double* ext_out, double* dG, double* stats,
+                             void* stream);
+
 /* d_p = V'^-1 (g_p - Wp^T dG), pose_out = pose_in - d_p; norms as camcal_backsub */
 int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
                        const double* Wp_all, double lam, const double* dG, const double* pose_in,

@@ -387,6 +387,28 @@ int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp, co
   else rig_pose_schur<14>(n_cams, P, Vp, gp, Wp, lam, Y, z);
   return 0;
 }
+int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uint8_t* mask_host, double lam,
+                             const double* intr_in, const double* ext_in, double* intr_out, double* ext_out,
+                             double* dG, double* stats, void*) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  const int n = n_cams * (ni + 6);
+  if (n > RIG_MAXN) return CAMCAL_E_BADARG;
+  unsigned long long mask = 0;
+  for (int i = 0; i < n; ++i) if (mask_host[i]) mask |= 1ull << i;
+  static RigSolveWs w;
+  const int nl = 64;
+  for (int l = 0; l < nl; ++l) rig_solve_build(l, nl, ni, n_cams, rec, mask, lam, w);
+  for (int l = 0; l < nl; ++l) rig_solve_scale(l, nl, n, w);
+  for (int k = 0; k < n; ++k) {
+    for (int l = 0; l < nl; ++l) rig_solve_chol_col(l, nl, n, k, w);
+    rig_solve_chol_diag(0, n, k, w);
+    for (int l = 0; l < nl; ++l) rig_solve_chol_update(l, nl, n, k, w);
+  }
+  rig_solve_substitute(n, w);
+  rig_solve_finish(ni, n_cams, mask, w, intr_in, ext_in, intr_out, ext_out, dG, stats);
+  return 0;
+}
 int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp,
                        double lam, const double* dG, const double* pin, double* pout, double* norms, double*, void*) {
   if (model == 0) rig_backsub<15>(n_cams, P, Vp, gp, Wp, lam, dG, pin, pout, norms);

@@ -19,3 +19,11 @@ E = info["engine"]
 intr, ext, poses = E.get_params(0)
 d = np.abs(poses - R.poses_true).max(axis=1)
 print("worst poses", np.argsort(-d)[:5], np.sort(-d)[:5])
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 10, 1e-7), cams=cams, n_poses=R.n_poses)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
