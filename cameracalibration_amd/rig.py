@@ -100,8 +100,12 @@ class RigEngine:
         # per-camera records [U|b|cost | U_ie|U_ee|b_e] followed by [C|d]: one all-reduce
         self.rec_len = nC * (self.NV + self.NX)
         self.rec = [torch.zeros(self.rec_len + self.nG * self.nG + self.nG, **f64) for _ in range(2)]
-        self.Y = torch.zeros(6 * P, self.nG, **f64)
-        self.z = torch.zeros(6 * P, **f64)
+        # Y^T Y is a (nG x 6P) x (6P x nG) product with a tiny output: split the long
+        # dimension into chunks so the library GEMM (batched) fills the device, then sum
+        self.chunk = 256
+        rows = (6 * P + self.chunk - 1) // self.chunk * self.chunk
+        self.Y = torch.zeros(rows, self.nG, **f64)          # rows beyond 6P stay zero
+        self.z = torch.zeros(rows, **f64)
         self.dG = torch.zeros(self.nG, **f64)
         self.norms = torch.zeros(2, **f64)
         self.gstats = torch.zeros(2, **f64)
@@ -162,8 +166,10 @@ class RigEngine:
                    self.gp[b].data_ptr(), self.Wp[b].data_ptr(), float(lam), self.Y.data_ptr(),
                    self.z.data_ptr(), self._stream())
         Cm, d = self.cd(b)
-        torch.matmul(self.Y.t(), self.Y, out=Cm)              # library GEMM (rocBLAS fp64)
-        torch.mv(self.Y.t(), self.z, out=d)
+        Yc = self.Y.view(-1, self.chunk, self.nG)
+        Yt = Yc.transpose(1, 2)
+        Cm.copy_(torch.matmul(Yt, Yc).sum(0))                 # batched library GEMM (rocBLAS fp64)
+        d.copy_(torch.matmul(Yt, self.z.view(-1, self.chunk, 1)).sum(0).view(-1))
 
     def cost(self, b):
         return sum(self.cam_rec(b, c)[0][self.NV - 1] for c in range(self.n_cams))
