@@ -4,21 +4,26 @@ HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := cameracalibration_amd/csrc
 
-all: lib hostemu oracle
+all: lib hostemu oracle examples
 
 lib: $(CSRC)/libcamcal.so
-$(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h include/camcal.h
+$(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h $(CSRC)/camcal_rig.h $(CSRC)/camcal_points.h include/camcal.h
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $< -o $@
 
 hostemu: tests/hostemu/libcamcal_hostemu.so
-tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h include/camcal.h
+tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h $(CSRC)/camcal_rig.h $(CSRC)/camcal_points.h include/camcal.h
 	g++ -O2 -std=c++17 -fPIC -shared $< -o $@
 
 oracle:
 	$(MAKE) -C oracle
 
+# pure C-ABI host program (no Python, no torch); run on the GPU box by tests/test_gpu_cabi.py
+examples: examples/cabi_fisheye
+examples/cabi_fisheye: examples/cabi_fisheye.cpp include/camcal.h $(CSRC)/libcamcal.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 $< -o $@ -L$(CSRC) -lcamcal -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
+
 clean:
-	rm -f $(CSRC)/libcamcal.so tests/hostemu/libcamcal_hostemu.so
+	rm -f $(CSRC)/libcamcal.so tests/hostemu/libcamcal_hostemu.so examples/cabi_fisheye
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib hostemu oracle clean
+.PHONY: all lib hostemu oracle examples clean

@@ -32,6 +32,7 @@ _SIGNATURES = {
     "camcal_glob_len": (C.c_int, [_I]),
     "camcal_schur_len": (C.c_int, [_I]),
     "camcal_scratch_len": (C.c_int64, [_I, _I]),
+    "camcal_layout": (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_pack_tiles": (C.c_int, [_P, _P, _P, _P, _TP, _P, _P]),
     "camcal_pose_init": (C.c_int, [_I, _TP, _P, _P, _P, _P]),
     "camcal_pose_refine": (C.c_int, [_I, _TP, _P, _P, _I, _D, _P, _P]),

@@ -13,6 +13,8 @@
 #include <stdint.h>
 
 #include "../../include/camcal.h"
+#include <algorithm>
+#include <vector>
 #include "camcal_lane.h"
 #include "camcal_rig.h"
 #include "camcal_points.h"
@@ -725,6 +727,37 @@ int64_t camcal_scratch_len(int model, int n_tiles) {
   (void)model;
   const int64_t a = (int64_t)MAX_NV * MAX_WAVES, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
   return (a > b ? a : b) + 2 * MAX_NV;   // + the reduced values ahead of their expansion
+}
+
+int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, int64_t* n_slots,
+                  int64_t* total_floats, int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off) {
+  if (n_views < 0 || (n_views > 0 && !n_per_view) || !n_tiles || !n_slots || !total_floats) return CAMCAL_E_BADARG;
+  const int64_t T = n_views > 0 ? (n_views + LANES - 1) / LANES : 1;
+  if (T > 2147483647) return CAMCAL_E_TOOBIG;
+  *n_tiles = (int32_t)T;
+  *n_slots = T * LANES;
+  std::vector<int32_t> order((size_t)n_views);
+  for (int64_t i = 0; i < n_views; ++i) {
+    if (n_per_view[i] < 0) return CAMCAL_E_BADARG;
+    order[(size_t)i] = (int32_t)i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_per_view[a] > n_per_view[b]; });
+  int64_t off = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    int32_t nmax = 0;
+    for (int l = 0; l < LANES; ++l) {
+      const int64_t s = t * LANES + l;
+      const int32_t v = s < n_views ? order[(size_t)s] : -1;
+      const int32_t n = v >= 0 ? n_per_view[v] : 0;
+      if (slot_view) { slot_view[s] = v; lane_n[s] = n; }
+      nmax = n > nmax ? n : nmax;
+    }
+    if (slot_view) { tile_nmax[t] = nmax; tile_off[t] = off; }
+    off += (int64_t)nmax * PT_COMP * LANES;
+  }
+  *total_floats = off;
+  if (slot_view && (!lane_n || !tile_nmax || !tile_off)) return CAMCAL_E_BADARG;
+  return 0;
 }
 
 int camcal_pack_tiles(const float* obj_xyz, const float* img_uv, const int64_t* view_ptr,

@@ -69,6 +69,17 @@ int camcal_schur_len(int model);
  * launched wavefronts) for a problem of n_tiles tiles. */
 int64_t camcal_scratch_len(int model, int n_tiles);
 
+/* Host-side layout of n_views views with the given corner counts (HOST pointers, no
+ * device work): views sorted by descending count (stable) fill the slots, 64 slots per
+ * tile.  Pass slot_view == NULL to query the sizes only.  Outputs: n_tiles, n_slots
+ * (= 64 n_tiles), total_floats (length of pts), slot_view [n_slots] (view of each slot,
+ * -1 = padding), lane_n [n_slots], tile_nmax [n_tiles], tile_off [n_tiles]; copy the four
+ * arrays to the device to fill camcal_tiles.  No reference counterpart (cv2 takes the
+ * per-view arrays as they are, camera_calib.py:74-77). */
+int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, int64_t* n_slots,
+                  int64_t* total_floats, int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax,
+                  int64_t* tile_off);
+
 /* Gather cv2-style AoS points into tiles.  obj_xyz [n_obs][3] f32, img_uv
  * [n_obs][2] f32, view_ptr [n_views+1] i64 (CSR), slot_view [n_slots] i32 =
  * view index placed in each slot or -1.  Writes tiles->pts (caller-allocated,

@@ -7,6 +7,7 @@
 // gloo backend at world_size 2.  The product never loads this library: its
 // loader (cameracalibration_amd/_lib.py) only opens the HIP build and fails
 // loudly when that is missing.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -260,6 +261,37 @@ int camcal_n_intr(int model) { return model == 0 ? 9 : model == 1 ? 8 : CAMCAL_E
 int camcal_glob_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni + 1; }
 int camcal_schur_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni; }
 int64_t camcal_scratch_len(int, int) { return 64; }
+
+int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, int64_t* n_slots,
+                  int64_t* total_floats, int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off) {
+  if (n_views < 0 || (n_views > 0 && !n_per_view) || !n_tiles || !n_slots || !total_floats) return CAMCAL_E_BADARG;
+  const int64_t T = n_views > 0 ? (n_views + LANES - 1) / LANES : 1;
+  if (T > 2147483647) return CAMCAL_E_TOOBIG;
+  *n_tiles = (int32_t)T;
+  *n_slots = T * LANES;
+  std::vector<int32_t> order((size_t)n_views);
+  for (int64_t i = 0; i < n_views; ++i) {
+    if (n_per_view[i] < 0) return CAMCAL_E_BADARG;
+    order[(size_t)i] = (int32_t)i;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_per_view[a] > n_per_view[b]; });
+  int64_t off = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    int32_t nmax = 0;
+    for (int l = 0; l < LANES; ++l) {
+      const int64_t s = t * LANES + l;
+      const int32_t v = s < n_views ? order[(size_t)s] : -1;
+      const int32_t n = v >= 0 ? n_per_view[v] : 0;
+      if (slot_view) { slot_view[s] = v; lane_n[s] = n; }
+      nmax = n > nmax ? n : nmax;
+    }
+    if (slot_view) { tile_nmax[t] = nmax; tile_off[t] = off; }
+    off += (int64_t)nmax * PT_COMP * LANES;
+  }
+  *total_floats = off;
+  if (slot_view && (!lane_n || !tile_nmax || !tile_off)) return CAMCAL_E_BADARG;
+  return 0;
+}
 
 int camcal_pack_tiles(const float* obj, const float* img, const int64_t* view_ptr, const int32_t* slot_view,
                       const camcal_tiles* t, float* out, void*) {

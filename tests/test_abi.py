@@ -42,3 +42,30 @@ def test_emulator_exports_the_same_abi(emu):
     for n in _declared():
         assert hasattr(emu.dll, n), n
     assert emu.is_emulator
+
+
+def test_host_layout_matches_python_layout():
+    """camcal_layout (host side of the C ABI, what a C caller uses) against
+    engine.make_layout (what the Python drop-in uses), both libraries."""
+    import ctypes as C
+    import numpy as np
+    from cameracalibration_amd import _lib
+    from cameracalibration_amd.engine import make_layout
+    rng = np.random.default_rng(0)
+    libs = [_lib.load(os.path.join(ROOT, "tests", "hostemu", "libcamcal_hostemu.so"))]
+    if os.path.exists(_lib.DEFAULT_PATH):
+        libs.append(_lib.load(_lib.DEFAULT_PATH))
+    for lib in libs:
+        for n_views in (0, 1, 63, 64, 65, 1000):
+            n = rng.integers(4, 89, n_views).astype(np.int32)
+            ref = make_layout(n)
+            nt, ns, tot = C.c_int32(), C.c_int64(), C.c_int64()
+            ptr = n.ctypes.data if n_views else None
+            assert lib.camcal_layout(n_views, ptr, C.byref(nt), C.byref(ns), C.byref(tot), None, None, None, None) == 0
+            assert (nt.value, ns.value, tot.value) == (ref["n_tiles"], ref["n_slots"], ref["total_floats"])
+            sv = np.empty(ns.value, np.int32); ln = np.empty(ns.value, np.int32)
+            nm = np.empty(nt.value, np.int32); to = np.empty(nt.value, np.int64)
+            assert lib.camcal_layout(n_views, ptr, C.byref(nt), C.byref(ns), C.byref(tot), sv.ctypes.data,
+                                     ln.ctypes.data, nm.ctypes.data, to.ctypes.data) == 0
+            assert np.array_equal(sv, ref["slot_view"]) and np.array_equal(ln, ref["lane_n"])
+            assert np.array_equal(nm, ref["tile_nmax"]) and np.array_equal(to, ref["tile_off"])
