@@ -66,6 +66,27 @@ def cpu_baseline(seconds_target=12.0):
         return {"value": None, "unit": "corner-obs/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
 
 
+def big_solve(name, n_views, dev, lib):
+    """Whole fisheye solve (pose initialisation + damped Gauss-Newton to the reference's
+    criteria) of a device-resident synthetic set, one run."""
+    from cameracalibration_amd import solver
+    P = synth.config(name, n_views=n_views, device=dev)
+    n_obs = P.n_obs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
+    E.set_intr(0, P.intr_guess())
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), (3, 1000, 1e-6))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    intr = E.get_intr(0)
+    return {"ms": ms, "iterations": it, "observations": n_obs, "rms_px": float(np.sqrt(cost / n_obs)),
+            "fx_rel_err": float(abs(intr[0] / P.K_true[0] - 1)), "note": "points already on the device; "
+            "includes packing, pose initialisation and every host round trip"}
+
+
 def solve_times(dev):
     """Wall-clock of whole solves through the drop-in API (SURVEY.md 8d asks for it
     next to the evaluation rate): median of 3 after one warm-up, host lists in,
@@ -121,6 +142,12 @@ def solve_times(dev):
         ms, info = med(c4)
         out["C4_rig_4x10000_poses"] = {"ms": ms, "iterations": info["iters"], "observations": R.n_obs,
                                         "note": "points already on the device"}
+        del R, cams
+        torch.cuda.empty_cache()
+        lib = _lib.load()
+        out["C3_fisheye_100k_ragged_views"] = big_solve("C3", 100_000, dev, lib)
+        torch.cuda.empty_cache()
+        out["C5_fisheye_1M_views"] = big_solve("C5", 1_000_000, dev, lib)
     except Exception as exc:      # reported, never required
         out["error"] = str(exc)
     return out
