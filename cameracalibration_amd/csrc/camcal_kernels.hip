@@ -14,6 +14,7 @@
 
 #include "../../include/camcal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 #include "camcal_lane.h"
 #include "camcal_rig.h"
@@ -400,23 +401,101 @@ __global__ void k_expand(const double* __restrict__ red, double* __restrict__ ou
   for (int i = 0; i < n_tail; ++i) out[NV + i] = red[NR + i];
 }
 
+// Per-view pose refinement (cv::internal::ComputeExtrinsicRefine's rule per view:
+// Gauss-Newton until ||d|| / ||x + d|| <= tol, at most max_iter steps).  Views
+// need very different numbers of steps (a few percent run to the cap), and a
+// wavefront that walks one view per lane is as slow as its slowest view.  So a
+// tile iterates lane-per-view only while at least STRAGGLER_LANES of its views
+// are still moving; the remaining ones are then finished one at a time by the
+// whole wavefront, the 64 lanes sharing the view's corners and butterfly-summing
+// the 27 sums of V and g (a step then costs ~1/12 of a lane-per-view step).
+// Measured on 1M views x 88 corners (first refinement at the guessed intrinsics):
+// lane-per-view only 12.3 ms; thresholds 4 / 8 / 16 / 32 lanes: 11.0 / 9.8 / 10.9 /
+// 13.0 ms at one wavefront per SIMD, 7.8 ms at 8 with the register cap for two.
+constexpr int STRAGGLER_LANES = 8;
+
 template <int MODEL, bool PLANAR>
-__global__ __launch_bounds__(TPB) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
+__device__ __forceinline__ bool wave_pose_gn_step(const float* base, int n, const double* intr, double pose[6],
+                                                  double& change, int lane) {
+  double R[9];
+  rodrigues(pose, R);
+  const double t[3] = {pose[3], pose[4], pose[5]};
+  double V[21], g[6];
+#pragma unroll
+  for (int i = 0; i < 21; ++i) V[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  for (int k = lane; k < n; k += LANES) {
+    const Obs o = load_obs<PLANAR>(base, k);
+    double Yr[3], Yc[3];
+    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+    PointEval<MODEL> p;
+    eval_point<true>(Yc, intr, p);
+    const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
+    double ju[6], jv[6];
+    pose_row(Yr, p.gu, ju);
+    pose_row(Yr, p.gv, jv);
+    accumulate_vg(V, g, ju, jv, eu, ev);
+  }
+#pragma unroll
+  for (int i = 0; i < 21; ++i) V[i] = wave_sum(V[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[i] = wave_sum(g[i]);
+  return pose_gn_update(V, g, pose, change);       // every lane holds the same sums: uniform
+}
+
+template <int MODEL, bool PLANAR>
+__global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
                                                      double* __restrict__ pose, int max_iter, double tol,
-                                                     int32_t* __restrict__ iters) {
+                                                     int32_t* __restrict__ iters, int straggler_lanes) {
   constexpr int NI = MT<MODEL>::NI;
   const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
   if (tile >= t.n_tiles) return;
   const int lane = threadIdx.x & 63;
   const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
   const LaneTile tv = lane_tile(t, tile, lane);
-  if (tv.n < 4) { if (iters) iters[slot] = 0; return; }
   double I[NI], p[6];
   load_intr<NI>(intr, I);
   load_pose(pose, S, slot, p);
-  const int it = lane_pose_refine<MODEL, PLANAR>(tv, I, p, max_iter, tol);
+  int it = 0;
+  double change = 1.0;
+  bool active = tv.n >= 4 && max_iter > 0 && change > tol;
+  // phase 1: one view per lane while enough of the tile's views are still moving
+  while (__popcll(__ballot(active)) >= straggler_lanes) {
+    if (active) {
+      const bool ok = lane_pose_gn_step<MODEL, PLANAR>(tv, I, p, change);
+      if (ok) ++it;
+      active = ok && change > tol && it < max_iter;
+    }
+  }
+  // phase 2: the wavefront finishes the stragglers one after the other
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int L = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    double q[6];
 #pragma unroll
-  for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+    for (int c = 0; c < 6; ++c) q[c] = __shfl(p[c], L, 64);
+    const int n = __shfl(tv.n, L, 64);
+    int jt = __shfl(it, L, 64);
+    double ch = 1.0;
+    const float* base = tv.base - lane + L;
+    bool go = true;
+    while (go) {
+      const bool ok = wave_pose_gn_step<MODEL, PLANAR>(base, n, I, q, ch, lane);
+      if (ok) ++jt;
+      go = ok && ch > tol && jt < max_iter;
+    }
+    if (lane == L) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) p[c] = q[c];
+      it = jt;
+    }
+  }
+  if (tv.n >= 4) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+  }
   if (iters) iters[slot] = it;
 }
 
@@ -787,7 +866,8 @@ int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr,
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const dim3 g(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_pose_refine<M, P>), g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters)
+  const int sl = STRAGGLER_LANES;
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_pose_refine<M, P>), g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, sl)
   DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
 #undef LAUNCH
   HIP_TRY(hipGetLastError());

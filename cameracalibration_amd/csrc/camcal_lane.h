@@ -191,50 +191,63 @@ CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double
 // restatement of cv::internal::ComputeExtrinsicRefine: x += -(J^T J)^-1 J^T e,
 // stop when ||d|| / ||x + d|| <= tol or after max_iter steps.  Returns the
 // number of steps taken.  (cv2's cond(J) > 1e6 early-out is not evaluated.)
+// finish of one Gauss-Newton pose step from the local-frame sums V, g: map to
+// Rodrigues coordinates, solve, update; returns false on a non-positive pivot
+CC_HD bool pose_gn_update(double V[21], double g[6], double pose[6], double& change) {
+  double Jl[9];
+  left_jacobian(pose, Jl);
+  vg_to_rodrigues_frame(Jl, V, g);
+  const bool ok = chol6(V);
+  chol6_fwd(V, g);
+  chol6_bwd(V, g);
+  if (!ok) return false;
+  double d2 = 0.0, x2 = 0.0;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    const double xn = pose[i] - g[i];
+    d2 += g[i] * g[i];
+    x2 += xn * xn;
+    pose[i] = xn;
+  }
+  change = sqrt(d2) / sqrt(x2);
+  return true;
+}
+
+// one Gauss-Newton step of one view walked by one lane
+template <int MODEL, bool PLANAR>
+CC_HD bool lane_pose_gn_step(const LaneTile& tv, const double* intr, double pose[6], double& change) {
+  double R[9];
+  rodrigues(pose, R);
+  const double t[3] = {pose[3], pose[4], pose[5]};
+  double V[21], g[6];
+  CC_UNROLL
+  for (int i = 0; i < 21; ++i) V[i] = 0.0;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  Obs cur = load_obs<PLANAR>(tv.base, 0);
+  for (int k = 0; k < tv.n; ++k) {
+    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.n) ? k + 1 : k);
+    double Yr[3], Yc[3];
+    transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+    PointEval<MODEL> p;
+    eval_point<true>(Yc, intr, p);
+    const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
+    double ju[6], jv[6];
+    pose_row(Yr, p.gu, ju);
+    pose_row(Yr, p.gv, jv);
+    accumulate_vg(V, g, ju, jv, eu, ev);
+    cur = nxt;
+  }
+  return pose_gn_update(V, g, pose, change);
+}
+
 template <int MODEL, bool PLANAR>
 CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6], int max_iter,
                            double tol) {
   int it = 0;
   double change = 1.0;
   while (change > tol && it < max_iter) {
-    double R[9];
-    rodrigues(pose, R);
-    const double t[3] = {pose[3], pose[4], pose[5]};
-    double V[21], g[6];
-    CC_UNROLL
-    for (int i = 0; i < 21; ++i) V[i] = 0.0;
-    CC_UNROLL
-    for (int i = 0; i < 6; ++i) g[i] = 0.0;
-    Obs cur = load_obs<PLANAR>(tv.base, 0);
-    for (int k = 0; k < tv.n; ++k) {
-      const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.n) ? k + 1 : k);
-      double Yr[3], Yc[3];
-      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
-      PointEval<MODEL> p;
-      eval_point<true>(Yc, intr, p);
-      const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
-      double ju[6], jv[6];
-      pose_row(Yr, p.gu, ju);
-      pose_row(Yr, p.gv, jv);
-      accumulate_vg(V, g, ju, jv, eu, ev);
-      cur = nxt;
-    }
-    double Jl[9];
-    left_jacobian(pose, Jl);
-    vg_to_rodrigues_frame(Jl, V, g);
-    const bool ok = chol6(V);
-    chol6_fwd(V, g);
-    chol6_bwd(V, g);
-    if (!ok) break;
-    double d2 = 0.0, x2 = 0.0;
-    CC_UNROLL
-    for (int i = 0; i < 6; ++i) {
-      const double xn = pose[i] - g[i];
-      d2 += g[i] * g[i];
-      x2 += xn * xn;
-      pose[i] = xn;
-    }
-    change = sqrt(d2) / sqrt(x2);
+    if (!lane_pose_gn_step<MODEL, PLANAR>(tv, intr, pose, change)) break;
     ++it;
   }
   return it;
