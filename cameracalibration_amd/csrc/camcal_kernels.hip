@@ -811,6 +811,7 @@ int64_t camcal_scratch_len(int model, int n_tiles) {
 int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, int64_t* n_slots,
                   int64_t* total_floats, int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off) {
   if (n_views < 0 || (n_views > 0 && !n_per_view) || !n_tiles || !n_slots || !total_floats) return CAMCAL_E_BADARG;
+  if (slot_view && (!lane_n || !tile_nmax || !tile_off)) return CAMCAL_E_BADARG;
   const int64_t T = n_views > 0 ? (n_views + LANES - 1) / LANES : 1;
   if (T > 2147483647) return CAMCAL_E_TOOBIG;
   *n_tiles = (int32_t)T;
@@ -835,7 +836,6 @@ int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, 
     off += (int64_t)nmax * PT_COMP * LANES;
   }
   *total_floats = off;
-  if (slot_view && (!lane_n || !tile_nmax || !tile_off)) return CAMCAL_E_BADARG;
   return 0;
 }
 

@@ -171,11 +171,14 @@ CC_HD void remap_pixel_u8(const unsigned char* src, int sw, int sh, long long ss
             w11 = fx * fy * 32;
   const bool x0 = ix >= 0 && ix < sw, x1 = ix + 1 >= 0 && ix + 1 < sw;
   const bool y0 = iy >= 0 && iy < sh, y1 = iy + 1 >= 0 && iy + 1 < sh;
-  const unsigned char* r0 = src + (long long)iy * sstride + (long long)ix * cn;
-  const unsigned char* r1 = r0 + sstride;
+  // offsets are formed only for neighbours inside the image
+  const long long o00 = (x0 && y0) ? (long long)iy * sstride + (long long)ix * cn : -1;
+  const long long o01 = (x1 && y0) ? (long long)iy * sstride + (long long)(ix + 1) * cn : -1;
+  const long long o10 = (x0 && y1) ? (long long)(iy + 1) * sstride + (long long)ix * cn : -1;
+  const long long o11 = (x1 && y1) ? (long long)(iy + 1) * sstride + (long long)(ix + 1) * cn : -1;
   for (int c = 0; c < cn; ++c) {
-    const int p00 = (x0 && y0) ? r0[c] : cval, p01 = (x1 && y0) ? r0[cn + c] : cval;
-    const int p10 = (x0 && y1) ? r1[c] : cval, p11 = (x1 && y1) ? r1[cn + c] : cval;
+    const int p00 = o00 >= 0 ? src[o00 + c] : cval, p01 = o01 >= 0 ? src[o01 + c] : cval;
+    const int p10 = o10 >= 0 ? src[o10 + c] : cval, p11 = o11 >= 0 ? src[o11 + c] : cval;
     const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
     dst[c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
   }
