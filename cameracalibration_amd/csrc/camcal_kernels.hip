@@ -406,17 +406,28 @@ __global__ void k_expand(const double* __restrict__ red, double* __restrict__ ou
 // need very different numbers of steps (a few percent run to the cap), and a
 // wavefront that walks one view per lane is as slow as its slowest view.  So a
 // tile iterates lane-per-view only while at least STRAGGLER_LANES of its views
-// are still moving; the remaining ones are then finished one at a time by the
-// whole wavefront, the 64 lanes sharing the view's corners and butterfly-summing
-// the 27 sums of V and g (a step then costs ~1/12 of a lane-per-view step).
+// are still moving.  The rest is finished cooperatively: the wavefront splits
+// into 64 / GROUP groups, each group takes stragglers from the tile's list in
+// turn, its GROUP lanes share the view's corners and butterfly-sum the 27 sums
+// of V and g.  Poses travel through global memory between the phases (a lane
+// of a finished group may be masked off, so no cross-lane reads are used).
 // Measured on 1M views x 88 corners (first refinement at the guessed intrinsics):
-// lane-per-view only 12.3 ms; thresholds 4 / 8 / 16 / 32 lanes: 11.0 / 9.8 / 10.9 /
-// 13.0 ms at one wavefront per SIMD, 7.8 ms at 8 with the register cap for two.
-constexpr int STRAGGLER_LANES = 8;
+// lane-per-view only 12.3 ms; whole-wavefront stragglers, threshold 8: 7.8 ms; groups
+// of 16 lanes, threshold 16: 7.1 ms (groups of 4 / 8 and thresholds 24..40 within 5 %).
+// One lane-per-view step of all views costs 0.75 ms and the mean view needs 5.8.
+constexpr int STRAGGLER_LANES = 16;
+constexpr int GROUP = 16;
+
+template <int G>
+__device__ __forceinline__ double group_sum(double x) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
 
 template <int MODEL, bool PLANAR>
-__device__ __forceinline__ bool wave_pose_gn_step(const float* base, int n, const double* intr, double pose[6],
-                                                  double& change, int lane) {
+__device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, const double* intr, double pose[6],
+                                                   double& change, int gl) {
   double R[9];
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
@@ -425,7 +436,7 @@ __device__ __forceinline__ bool wave_pose_gn_step(const float* base, int n, cons
   for (int i = 0; i < 21; ++i) V[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  for (int k = lane; k < n; k += LANES) {
+  for (int k = gl; k < n; k += GROUP) {
     const Obs o = load_obs<PLANAR>(base, k);
     double Yr[3], Yc[3];
     transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
@@ -438,21 +449,21 @@ __device__ __forceinline__ bool wave_pose_gn_step(const float* base, int n, cons
     accumulate_vg(V, g, ju, jv, eu, ev);
   }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) V[i] = wave_sum(V[i]);
+  for (int i = 0; i < 21; ++i) V[i] = group_sum<GROUP>(V[i]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) g[i] = wave_sum(g[i]);
-  return pose_gn_update(V, g, pose, change);       // every lane holds the same sums: uniform
+  for (int i = 0; i < 6; ++i) g[i] = group_sum<GROUP>(g[i]);
+  return pose_gn_update(V, g, pose, change);       // every lane of the group holds the same sums
 }
 
 template <int MODEL, bool PLANAR>
 __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
-                                                     double* __restrict__ pose, int max_iter, double tol,
-                                                     int32_t* __restrict__ iters, int straggler_lanes) {
+                                                        double* __restrict__ pose, int max_iter, double tol,
+                                                        int32_t* __restrict__ iters, int straggler_lanes) {
   constexpr int NI = MT<MODEL>::NI;
   const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
   if (tile >= t.n_tiles) return;
   const int lane = threadIdx.x & 63;
-  const int64_t S = t.n_slots, slot = (int64_t)tile * LANES + lane;
+  const int64_t S = t.n_slots, slot0 = (int64_t)tile * LANES, slot = slot0 + lane;
   const LaneTile tv = lane_tile(t, tile, lane);
   double I[NI], p[6];
   load_intr<NI>(intr, I);
@@ -468,35 +479,54 @@ __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const do
       active = ok && change > tol && it < max_iter;
     }
   }
-  // phase 2: the wavefront finishes the stragglers one after the other
-  unsigned long long todo = __ballot(active);
-  while (todo) {
-    const int L = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
+  const unsigned long long todo = __ballot(active);
+  if (todo == 0) {
+    if (tv.n >= 4) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+    }
+    if (iters) iters[slot] = it;
+    return;
+  }
+  // phase 2: groups of GROUP lanes finish the stragglers; poses and counts travel through LDS
+  __shared__ int s_it[TPB];
+  __shared__ double s_pose[6][TPB];
+  const int w0 = threadIdx.x & ~63;
+  s_it[threadIdx.x] = it;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) s_pose[c][threadIdx.x] = p[c];
+  __threadfence_block();                      // visible to the other lanes of the wave
+  const int grp = lane / GROUP, gl = lane % GROUP;
+  const int count = __popcll(todo);
+  for (int s = grp; s < count; s += LANES / GROUP) {
+    unsigned long long m = todo;
+    for (int i = 0; i < s; ++i) m &= m - 1;
+    const int L = __ffsll((long long)m) - 1;
     double q[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) q[c] = __shfl(p[c], L, 64);
-    const int n = __shfl(tv.n, L, 64);
-    int jt = __shfl(it, L, 64);
+    for (int c = 0; c < 6; ++c) q[c] = s_pose[c][w0 + L];
+    const int n = t.lane_n[slot0 + L];
+    int jt = s_it[w0 + L];
     double ch = 1.0;
     const float* base = tv.base - lane + L;
     bool go = true;
     while (go) {
-      const bool ok = wave_pose_gn_step<MODEL, PLANAR>(base, n, I, q, ch, lane);
+      const bool ok = group_pose_gn_step<MODEL, PLANAR>(base, n, I, q, ch, gl);
       if (ok) ++jt;
       go = ok && ch > tol && jt < max_iter;
     }
-    if (lane == L) {
+    if (gl == 0) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) p[c] = q[c];
-      it = jt;
+      for (int c = 0; c < 6; ++c) s_pose[c][w0 + L] = q[c];
+      s_it[w0 + L] = jt;
     }
   }
+  __threadfence_block();
   if (tv.n >= 4) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+    for (int c = 0; c < 6; ++c) pose[c * S + slot] = s_pose[c][threadIdx.x];
   }
-  if (iters) iters[slot] = it;
+  if (iters) iters[slot] = s_it[threadIdx.x];
 }
 
 template <int MODEL>
