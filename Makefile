@@ -3,12 +3,15 @@
 HIPCC ?= hipcc
 ARCH  ?= gfx950
 CSRC  := cameracalibration_amd/csrc
+# the GCN register-pressure trackers keep 9 more accumulator words of the single-pass
+# kernel in architectural VGPRs (481 instead of 499 instructions per observation, -2.5 % time)
+HIPFLAGS_EXTRA ?= -mllvm -amdgpu-use-amdgpu-trackers=1
 
 all: lib hostemu oracle examples
 
 lib: $(CSRC)/libcamcal.so
 $(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h $(CSRC)/camcal_rig.h $(CSRC)/camcal_points.h include/camcal.h
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS_EXTRA) $< -o $@
 
 hostemu: tests/hostemu/libcamcal_hostemu.so
 tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h $(CSRC)/camcal_rig.h $(CSRC)/camcal_points.h include/camcal.h
