@@ -215,9 +215,12 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
   const double x = Yc[0] * iz, y = Yc[1] * iz;
   const double r2 = x * x + y * y;
   const bool big = r2 > 1e-16;                   // cv2: r > 1e-8
+  // one reciprocal square root serves both branches: on the axis (r <= 1e-8, where cv2
+  // switches to cdist = 1) the argument is scaled by 2^600 so that it stays normal, and
+  // an exact zero is floored (r = 2^-500 instead of 0: every term it feeds vanishes)
   double rr;
-  double inv_r = fast_rsqrt(big ? r2 : 1.0, rr);
-  rr = big ? rr : sqrt(r2);
+  double inv_r = fast_rsqrt(big ? r2 : fmax(r2 * 0x1p600, 0x1p-400), rr);
+  rr = big ? rr : rr * 0x1p-300;
   inv_r = big ? inv_r : 1.0;
   const double th = atan_pos(rr);
   const double th2 = th * th;
