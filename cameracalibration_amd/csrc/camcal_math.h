@@ -103,6 +103,21 @@ CC_HD double fast_rsqrt(double a, double& rt) {
 // and an 11-term odd polynomial (Chebyshev-node fit, max relative error
 // 5e-18 before rounding; coefficients from mpmath, tools/atan_coeffs.py).
 // Fewer constants than the 20-term libm form, which matters for registers.
+// On the device the coefficients are read from a (non-const) table: the loads are
+// uniform and loop invariant, so they become scalar loads hoisted out of the corner
+// loop and the coefficients stay in SGPRs, where an FMA can read them directly.  As
+// literals they occupy 20 VGPRs for the whole loop plus a copy per Horner step.
+#define CAMCAL_ATAN_COEFFS                                                                            \
+  -0.019176887119062258989, 0.039231658295587191303, -0.050854497379402598613,                      \
+  0.058581489128022098816, -0.066645114473819480001, 0.076921831908260865637,                       \
+  -0.090909045781239018905, 0.11111111015256361727, -0.14285714284666542922,                        \
+  0.19999999999995520678, -0.3333333333333333016
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ double camcal_atan_c[11] = {CAMCAL_ATAN_COEFFS};
+#else
+static const double camcal_atan_c[11] = {CAMCAL_ATAN_COEFFS};
+#endif
+
 CC_HD double atan_pos(double x) {
   const bool hi = x > 2.414213562373095, mid = x > 0.41421356237309503;
   const double num = hi ? -1.0 : (mid ? x - 1.0 : x);
@@ -110,17 +125,9 @@ CC_HD double atan_pos(double x) {
   const double base = hi ? 1.5707963267948966 : (mid ? 0.78539816339744831 : 0.0);
   const double t = num * fast_rcp(den);
   const double z = t * t;
-  double p = -0.019176887119062258989;
-  p = fma(p, z, 0.039231658295587191303);
-  p = fma(p, z, -0.050854497379402598613);
-  p = fma(p, z, 0.058581489128022098816);
-  p = fma(p, z, -0.066645114473819480001);
-  p = fma(p, z, 0.076921831908260865637);
-  p = fma(p, z, -0.090909045781239018905);
-  p = fma(p, z, 0.11111111015256361727);
-  p = fma(p, z, -0.14285714284666542922);
-  p = fma(p, z, 0.19999999999995520678);
-  p = fma(p, z, -0.3333333333333333016);
+  double p = camcal_atan_c[0];
+  CC_UNROLL
+  for (int i = 1; i < 11; ++i) p = fma(p, z, camcal_atan_c[i]);
   return base + fma(t * z, p, t);
 }
 
