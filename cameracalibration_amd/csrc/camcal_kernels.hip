@@ -73,11 +73,15 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double* __restrict__ scr
   if (threadIdx.x == 0) out[i] = sh[0];
 }
 
+// The tile index is the same for the 64 lanes of a wavefront; saying so lets the
+// tile's offset and loop bound be scalar loads and the corner loop run on SALU
+// compares with SGPR-based addressing.
 __device__ __forceinline__ LaneTile lane_tile(const camcal_tiles& t, int tile, int lane) {
+  const int ut = __builtin_amdgcn_readfirstlane(tile);
   LaneTile tv;
-  tv.base = t.pts + t.tile_off[tile] + lane;
-  tv.n = t.lane_n[(int64_t)tile * LANES + lane];
-  tv.nmax = t.tile_nmax[tile];
+  tv.base = t.pts + t.tile_off[ut] + lane;
+  tv.n = t.lane_n[(int64_t)ut * LANES + lane];
+  tv.nmax = t.tile_nmax[ut];
   return tv;
 }
 
