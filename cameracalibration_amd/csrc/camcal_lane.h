@@ -61,20 +61,26 @@ CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const doubl
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   acc.zero();
-  Obs cur = load_obs<PLANAR>(tv.base, 0);
-  for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
-    if (k < tv.n) {
-      double Yr[3], Yc[3];
-      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
-      PointEval<MODEL> p;
-      eval_point<true>(Yc, intr, p);
-      const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
-      accumulate_intr(gacc, p, eu, ev);
-      accumulate_view(acc, p, Yr, eu, ev);
-    }
-    cur = nxt;
+  auto one = [&](const Obs& o) {
+    double Yr[3], Yc[3];
+    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+    PointEval<MODEL> p;
+    eval_point<true>(Yc, intr, p);
+    const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
+    accumulate_intr(gacc, p, eu, ev);
+    accumulate_view(acc, p, Yr, eu, ev);
+  };
+  // two corners per trip, each loaded one step ahead of its use (no register rotation)
+  const int last = tv.nmax - 1;
+  Obs a = load_obs<PLANAR>(tv.base, 0);
+  int k = 0;
+  for (; k + 1 < tv.nmax; k += 2) {
+    const Obs b = load_obs<PLANAR>(tv.base, k + 1);
+    if (k < tv.n) one(a);
+    a = load_obs<PLANAR>(tv.base, k + 2 < last ? k + 2 : last);
+    if (k + 1 < tv.n) one(b);
   }
+  if (k < tv.nmax && k < tv.n) one(a);
   gacc.add_count(tv.n);
   if (!LOCAL) {
     double Jl[9];
