@@ -221,18 +221,18 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
   const double iz = fast_rcp(Yc[2]);
   const double x = Yc[0] * iz, y = Yc[1] * iz;
   const double r2 = x * x + y * y;
-  const bool big = r2 > 1e-16;                   // cv2: r > 1e-8
-  // one reciprocal square root serves both branches: on the axis (r <= 1e-8, where cv2
-  // switches to cdist = 1) the argument is scaled by 2^600 so that it stays normal, and
-  // an exact zero is floored (r = 2^-500 instead of 0: every term it feeds vanishes)
+  // cv2 switches to cdist = 1 for r <= 1e-8.  Here such a point is evaluated by the general
+  // formulas at r = 1e-8 instead (one v_max instead of a compare and fourteen selects per
+  // corner): theta_d / r is then 1 to rounding, and the terms that are inaccurate at that
+  // radius (q) only enter multiplied by x^2, x y, y^2 <= 1e-16 -- the result differs from
+  // cv2's special case by less than 1e-15 relative.
+  const double r2c = fmax(r2, 1e-16);
   double rr;
-  double inv_r = fast_rsqrt(big ? r2 : fmax(r2 * 0x1p600, 0x1p-400), rr);
-  rr = big ? rr : rr * 0x1p-300;
-  inv_r = big ? inv_r : 1.0;
+  const double inv_r = fast_rsqrt(r2c, rr);
   const double th = atan_pos(rr);
   const double th2 = th * th;
   const double poly = 1.0 + th2 * (k1 + th2 * (k2 + th2 * (k3 + th2 * k4)));
-  const double cdist = big ? th * poly * inv_r : 1.0;
+  const double cdist = th * poly * inv_r;
   const double xd = x * cdist, yd = y * cdist;
   o.pu = xd * fx + cx;
   o.pv = yd * fy + cy;
@@ -248,7 +248,7 @@ CC_HD void eval_point(const double Yc[3], const double* intr, PointEval<FISHEYE>
     o.au[5] = fxx * tp; o.av[5] = fyy * tp;
     const double dpoly = 1.0 + th2 * (3.0 * k1 + th2 * (5.0 * k2 + th2 * (7.0 * k3 + th2 * 9.0 * k4)));
     // s(r) = theta_d / r ;  q = (ds/dr)/r
-    const double q = big ? (dpoly * fast_rcp(1.0 + r2) - cdist) * inv_r * inv_r : 0.0;
+    const double q = (dpoly * fast_rcp(1.0 + r2) - cdist) * inv_r * inv_r;
     const double a = cdist + x * x * q, b = x * y * q, c = cdist + y * y * q;
     const double fxz = fx * iz, fyz = fy * iz;
     o.gu[0] = fxz * a; o.gu[1] = fxz * b; o.gu[2] = -fxz * (x * a + y * b);

@@ -293,3 +293,41 @@ def case_remap():
 
 
 ALL.append(case_remap)
+
+
+def case_on_axis_point():
+    """cv2 switches to cdist = 1 for points within 1e-8 of the optical axis; the kernels
+    evaluate them by the general formula at r = 1e-8 (camcal_math.h).  The projection and
+    the normal-equation blocks of a view that contains such a point match the oracle."""
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    K4, D = synth.FISHEYE_TRUE_K, np.array(synth.FISHEYE_TRUE_D)
+    X = np.array([[0.0, 0.0, 0.0], [1e-7, 0.0, 0.0], [25.0, 0.0, 0.0], [0.0, 25.0, 0.0], [25.0, 25.0, 0.0],
+                  [50.0, 25.0, 0.0]])
+    pose = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 500.0])          # first point exactly on the axis
+    got, _ = cc.fisheye.projectPoints(X.reshape(-1, 1, 3), pose[:3], pose[3:], Kmat(K4), D)
+    ref = M.project_fisheye(X, pose[:3], pose[3:], K4, D)
+    assert np.all(np.isfinite(got)) and np.abs(got.reshape(-1, 2) - ref).max() < 1e-9
+    assert np.allclose(got[0, 0], [K4[2], K4[3]], atol=1e-12)
+    obj = X.astype(np.float32)
+    img = (ref + 0.1).astype(np.float32)
+    E = Engine(_lib.FISHEYE, np.array([0, 6]), obj, img, dev, lib=lib)
+    intr = np.concatenate([K4, D])
+    E.set_intr(0, intr)
+    E.set_poses(0, pose[None])
+    E.normal_eq(0, 0, 0.0, store_blocks=True, fused=True)
+    blk = O.normal_blocks("fisheye", O.Views([obj.reshape(-1, 1, 3)], [img.reshape(-1, 1, 2)]), intr, pose[None])
+    G = E.glob[0].cpu().numpy()
+    U = np.zeros((8, 8))
+    U[np.triu_indices(8)] = G[:36]
+    U = U + U.T - np.diag(np.diag(U))
+    assert np.all(np.isfinite(G))
+    assert np.abs(U - blk["U"]).max() < 1e-11 * np.abs(blk["U"]).max()
+    assert np.abs(G[36:44] - blk["b"]).max() < 1e-10 * np.abs(blk["b"]).max()
+    i6 = np.triu_indices(6)
+    V = E.slots_to_views(E.V.T)[0]
+    assert np.abs(V - blk["V"][0][i6]).max() < 1e-11 * np.abs(blk["V"]).max()
+
+
+ALL.append(case_on_axis_point)
