@@ -24,6 +24,23 @@ CC_HD Obs load_obs(const float* base, int k) {
   return o;
 }
 
+// Walk the corners of the lane's view: f(obs) for k < n.  The trip count is the tile's
+// nmax (uniform over the wavefront); two corners per trip, each loaded one step ahead of
+// its use, so the loads overlap the arithmetic and no register rotation is needed.
+template <bool PLANAR, class F>
+CC_HD void for_each_obs(const LaneTile& tv, F&& f) {
+  const int last = tv.nmax - 1;
+  Obs a = load_obs<PLANAR>(tv.base, 0);
+  int k = 0;
+  for (; k + 1 < tv.nmax; k += 2) {
+    const Obs b = load_obs<PLANAR>(tv.base, k + 1);
+    if (k < tv.n) f(a);
+    a = load_obs<PLANAR>(tv.base, k + 2 < last ? k + 2 : last);
+    if (k + 1 < tv.n) f(b);
+  }
+  if (k < tv.nmax && k < tv.n) f(a);
+}
+
 // ---------------------------------------------------------------------------
 // K1: per-view blocks V, W, g of the normal equations (Rodrigues frame).
 template <int MODEL, bool PLANAR>
@@ -33,18 +50,13 @@ CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   acc.zero();
-  Obs cur = load_obs<PLANAR>(tv.base, 0);
-  for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);   // software prefetch
-    if (k < tv.n) {
-      double Yr[3], Yc[3];
-      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
-      PointEval<MODEL> p;
-      eval_point<true>(Yc, intr, p);
-      accumulate_view(acc, p, Yr, p.pu - (double)cur.u, p.pv - (double)cur.v);
-    }
-    cur = nxt;
-  }
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
+    double Yr[3], Yc[3];
+    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+    PointEval<MODEL> p;
+    eval_point<true>(Yc, intr, p);
+    accumulate_view(acc, p, Yr, p.pu - (double)o.u, p.pv - (double)o.v);
+  });
   double Jl[9];
   left_jacobian(pose, Jl);
   to_rodrigues_frame<MT<MODEL>::NI>(Jl, acc.V, acc.W, acc.g);
@@ -61,7 +73,7 @@ CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const doubl
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   acc.zero();
-  auto one = [&](const Obs& o) {
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
     double Yr[3], Yc[3];
     transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
     PointEval<MODEL> p;
@@ -69,18 +81,7 @@ CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const doubl
     const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
     accumulate_intr(gacc, p, eu, ev);
     accumulate_view(acc, p, Yr, eu, ev);
-  };
-  // two corners per trip, each loaded one step ahead of its use (no register rotation)
-  const int last = tv.nmax - 1;
-  Obs a = load_obs<PLANAR>(tv.base, 0);
-  int k = 0;
-  for (; k + 1 < tv.nmax; k += 2) {
-    const Obs b = load_obs<PLANAR>(tv.base, k + 1);
-    if (k < tv.n) one(a);
-    a = load_obs<PLANAR>(tv.base, k + 2 < last ? k + 2 : last);
-    if (k + 1 < tv.n) one(b);
-  }
-  if (k < tv.nmax && k < tv.n) one(a);
+  });
   gacc.add_count(tv.n);
   if (!LOCAL) {
     double Jl[9];
@@ -132,27 +133,22 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
     CC_UNROLL
     for (int i = 0; i < 6; ++i) g[i] = 0.0;
   }
-  Obs cur = load_obs<PLANAR>(tv.base, 0);
-  for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
-    if (k < tv.n) {
-      double Yr[3], Yc[3];
-      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
-      PointEval<MODEL> p;
-      eval_point<(MODE > 0)>(Yc, intr, p);
-      const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
-      if (MODE > 0) accumulate_intr(acc, p, eu, ev);
-      if (MODE == 2) {
-        double ju[6], jv[6];
-        pose_row(Yr, p.gu, ju);
-        pose_row(Yr, p.gv, jv);
-        accumulate_vg(V, g, ju, jv, eu, ev);
-      }
-      vc = fma(eu, eu, vc);
-      vc = fma(ev, ev, vc);
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
+    double Yr[3], Yc[3];
+    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+    PointEval<MODEL> p;
+    eval_point<(MODE > 0)>(Yc, intr, p);
+    const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
+    if (MODE > 0) accumulate_intr(acc, p, eu, ev);
+    if (MODE == 2) {
+      double ju[6], jv[6];
+      pose_row(Yr, p.gu, ju);
+      pose_row(Yr, p.gv, jv);
+      accumulate_vg(V, g, ju, jv, eu, ev);
     }
-    cur = nxt;
-  }
+    vc = fma(eu, eu, vc);
+    vc = fma(ev, ev, vc);
+  });
   if (MODE > 0) acc.add_count(tv.n);
   else acc.v[IntrAcc<MODEL>::COST] += vc;
   if (MODE == 2) {
@@ -172,21 +168,16 @@ CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double
   const double t[3] = {pose[3], pose[4], pose[5]};
   CC_UNROLL
   for (int i = 0; i < NI * 6; ++i) W[i] = 0.0;
-  Obs cur = load_obs<PLANAR>(tv.base, 0);
-  for (int k = 0; k < tv.nmax; ++k) {
-    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.nmax) ? k + 1 : k);
-    if (k < tv.n) {
-      double Yr[3], Yc[3];
-      transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
-      PointEval<MODEL> p;
-      eval_point<true>(Yc, intr, p);
-      double ju[6], jv[6];
-      pose_row(Yr, p.gu, ju);
-      pose_row(Yr, p.gv, jv);
-      accumulate_w(W, p, ju, jv);
-    }
-    cur = nxt;
-  }
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
+    double Yr[3], Yc[3];
+    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+    PointEval<MODEL> p;
+    eval_point<true>(Yc, intr, p);
+    double ju[6], jv[6];
+    pose_row(Yr, p.gu, ju);
+    pose_row(Yr, p.gv, jv);
+    accumulate_w(W, p, ju, jv);
+  });
   double Jl[9];
   left_jacobian(pose, Jl);
   w_to_rodrigues_frame<NI>(Jl, W);
@@ -230,20 +221,17 @@ CC_HD bool lane_pose_gn_step(const LaneTile& tv, const double* intr, double pose
   for (int i = 0; i < 21; ++i) V[i] = 0.0;
   CC_UNROLL
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  Obs cur = load_obs<PLANAR>(tv.base, 0);
-  for (int k = 0; k < tv.n; ++k) {
-    const Obs nxt = load_obs<PLANAR>(tv.base, (k + 1 < tv.n) ? k + 1 : k);
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
     double Yr[3], Yc[3];
-    transform_point<PLANAR>(R, t, cur.X, cur.Y, cur.Z, Yr, Yc);
+    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
     PointEval<MODEL> p;
     eval_point<true>(Yc, intr, p);
-    const double eu = p.pu - (double)cur.u, ev = p.pv - (double)cur.v;
+    const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
     double ju[6], jv[6];
     pose_row(Yr, p.gu, ju);
     pose_row(Yr, p.gv, jv);
     accumulate_vg(V, g, ju, jv, eu, ev);
-    cur = nxt;
-  }
+  });
   return pose_gn_update(V, g, pose, change);
 }
 
