@@ -119,16 +119,17 @@ static const double camcal_atan_c[11] = {CAMCAL_ATAN_COEFFS};
 #endif
 
 CC_HD double atan_pos(double x) {
+  // t = x, (x-1)/(x+1), -1/x on the three ranges, written t = (a x + b) / (c x + a) so that
+  // only the constants 0 / +-1 are selected (one conditional move each); the offset is
+  // (c + 1 - a) pi/4 = 0, pi/4, pi/2, an exact product
   const bool hi = x > 2.414213562373095, mid = x > 0.41421356237309503;
-  const double num = hi ? -1.0 : (mid ? x - 1.0 : x);
-  const double den = hi ? x : (mid ? x + 1.0 : 1.0);
-  const double base = hi ? 1.5707963267948966 : (mid ? 0.78539816339744831 : 0.0);
-  const double t = num * fast_rcp(den);
+  const double a = hi ? 0.0 : 1.0, b = mid ? -1.0 : 0.0, c = mid ? 1.0 : 0.0;
+  const double t = fma(x, a, b) * fast_rcp(fma(x, c, a));
   const double z = t * t;
   double p = camcal_atan_c[0];
   CC_UNROLL
   for (int i = 1; i < 11; ++i) p = fma(p, z, camcal_atan_c[i]);
-  return base + fma(t * z, p, t);
+  return fma(c + (1.0 - a), 0.78539816339744831, fma(t * z, p, t));
 }
 
 // ---------------------------------------------------------------------------
