@@ -25,6 +25,9 @@
  *   - per-slot arrays are component-major: pose[c*n_slots + s], c = r0 r1 r2 t0 t1 t2;
  *     V[e*n_slots + s] (21 upper-triangle entries of the 6x6 pose block),
  *     W[(a*6 + c)*n_slots + s] (NI x 6), g[c*n_slots + s]
+ *   - fisheye: a point within 1e-8 of the optical axis (where cv2 switches to
+ *     cdist = 1) is evaluated by the general formulas at r = 1e-8, which differs
+ *     from cv2's special case by less than 1e-15 relative
  *   - all functions return 0 on success, a hipError_t (> 0) if a HIP call
  *     failed, or a negative CAMCAL_E_* code for rejected arguments.
  */
