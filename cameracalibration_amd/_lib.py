@@ -28,6 +28,7 @@ _TP = C.POINTER(Tiles)
 
 _SIGNATURES = {
     "camcal_version": (C.c_int, []),
+    "camcal_set_lanes_per_view": (C.c_int, [C.c_int]),
     "camcal_n_intr": (C.c_int, [_I]),
     "camcal_glob_len": (C.c_int, [_I]),
     "camcal_schur_len": (C.c_int, [_I]),

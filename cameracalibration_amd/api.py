@@ -111,21 +111,35 @@ def _gather_views(object_points, image_points, min_points=4):
     if nv == 0 or nv != ni:
         raise error("objectPoints and imagePoints must be non-empty and of equal length "
                     "(nimages > 0 && nimages == (int)imagePoints.total())")
-    objs, imgs, counts = [], [], []
-    for o, i in zip(object_points, image_points):
-        o = np.asarray(o)
-        i = np.asarray(i)
-        if o.size % 3 or i.size % 2:
+    if all(type(o) is np.ndarray for o in object_points) and all(type(i) is np.ndarray for i in image_points):
+        # the usual call: lists of ndarrays -- sizes and one concatenation, no per-view conversions
+        so = np.fromiter((o.size for o in object_points), dtype=np.int64, count=nv)
+        si = np.fromiter((i.size for i in image_points), dtype=np.int64, count=nv)
+        if np.any(so % 3) or np.any(si % 2):
             raise error("objectPoints must be Nx3 / imagePoints Nx2")
-        o = o.reshape(-1, 3).astype(np.float32, copy=False)
-        i = i.reshape(-1, 2).astype(np.float32, copy=False)
-        if o.shape[0] != i.shape[0]:
+        counts = so // 3
+        if np.any(counts != si // 2):
             raise error("number of object and image points must be equal in every view")
-        if o.shape[0] < min_points:
+        if np.any(counts < min_points):
             raise error("every view needs at least %d points" % min_points)
-        objs.append(o)
-        imgs.append(i)
-        counts.append(o.shape[0])
+        objs = [np.concatenate([o.ravel() for o in object_points]).astype(np.float32, copy=False).reshape(-1, 3)]
+        imgs = [np.concatenate([i.ravel() for i in image_points]).astype(np.float32, copy=False).reshape(-1, 2)]
+    else:
+        objs, imgs, counts = [], [], []
+        for o, i in zip(object_points, image_points):
+            o = np.asarray(o)
+            i = np.asarray(i)
+            if o.size % 3 or i.size % 2:
+                raise error("objectPoints must be Nx3 / imagePoints Nx2")
+            o = o.reshape(-1, 3).astype(np.float32, copy=False)
+            i = i.reshape(-1, 2).astype(np.float32, copy=False)
+            if o.shape[0] != i.shape[0]:
+                raise error("number of object and image points must be equal in every view")
+            if o.shape[0] < min_points:
+                raise error("every view needs at least %d points" % min_points)
+            objs.append(o)
+            imgs.append(i)
+            counts.append(o.shape[0])
     view_ptr = np.zeros(nv + 1, dtype=np.int64)
     view_ptr[1:] = np.cumsum(counts)
     obj = np.concatenate(objs, axis=0)
@@ -148,8 +162,10 @@ def _write_back(dst, values):
 
 
 def _poses_to_tuples(poses):
-    rvecs = tuple(np.ascontiguousarray(p[:3].reshape(3, 1)) for p in poses)
-    tvecs = tuple(np.ascontiguousarray(p[3:].reshape(3, 1)) for p in poses)
+    """(N, 6) -> cv2's tuples of (3, 1) arrays (each a contiguous slice of one block)."""
+    n = poses.shape[0]
+    rvecs = tuple(np.ascontiguousarray(poses[:, :3]).reshape(n, 3, 1))
+    tvecs = tuple(np.ascontiguousarray(poses[:, 3:]).reshape(n, 3, 1))
     return rvecs, tvecs
 
 

@@ -429,7 +429,7 @@ __device__ __forceinline__ double group_sum(double x) {
   return x;
 }
 
-template <int MODEL, bool PLANAR>
+template <int MODEL, bool PLANAR, int G>
 __device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, const double* intr, double pose[6],
                                                    double& change, int gl) {
   double R[9];
@@ -440,7 +440,7 @@ __device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, con
   for (int i = 0; i < 21; ++i) V[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  for (int k = gl; k < n; k += GROUP) {
+  for (int k = gl; k < n; k += G) {
     const Obs o = load_obs<PLANAR>(base, k);
     double Yr[3], Yc[3];
     transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
@@ -453,9 +453,9 @@ __device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, con
     accumulate_vg(V, g, ju, jv, eu, ev);
   }
 #pragma unroll
-  for (int i = 0; i < 21; ++i) V[i] = group_sum<GROUP>(V[i]);
+  for (int i = 0; i < 21; ++i) V[i] = group_sum<G>(V[i]);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) g[i] = group_sum<GROUP>(g[i]);
+  for (int i = 0; i < 6; ++i) g[i] = group_sum<G>(g[i]);
   return pose_gn_update(V, g, pose, change);       // every lane of the group holds the same sums
 }
 
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const do
     const float* base = tv.base - lane + L;
     bool go = true;
     while (go) {
-      const bool ok = group_pose_gn_step<MODEL, PLANAR>(base, n, I, q, ch, gl);
+      const bool ok = group_pose_gn_step<MODEL, PLANAR, GROUP>(base, n, I, q, ch, gl);
       if (ok) ++jt;
       go = ok && ch > tol && jt < max_iter;
     }
@@ -531,6 +531,247 @@ __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const do
     for (int c = 0; c < 6; ++c) pose[c * S + slot] = s_pose[c][threadIdx.x];
   }
   if (iters) iters[slot] = s_it[threadIdx.x];
+}
+
+// Small view sets (group_lanes() below): G lanes share one view from the start, so a
+// production-sized call (20 ... a few thousand views) spreads over the whole chip
+// instead of a handful of wavefronts that each walk their views' corners serially.
+struct GroupView {
+  int64_t slot;        // the view's slot
+  const float* base;   // pts + tile_off + lane-of-the-view
+  int n;               // its corners
+  int gl;              // this lane's rank in the group
+};
+
+template <int G>
+__device__ __forceinline__ bool group_view(const camcal_tiles& t, GroupView& gv) {
+  gv.slot = ((int64_t)blockIdx.x * TPB + threadIdx.x) / G;
+  gv.gl = threadIdx.x % G;
+  if (gv.slot >= t.n_slots) return false;
+  gv.base = t.pts + t.tile_off[gv.slot / LANES] + (gv.slot % LANES);
+  gv.n = t.lane_n[gv.slot];
+  return true;
+}
+
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                         double* __restrict__ pose, int max_iter, double tol,
+                                                         int32_t* __restrict__ iters) {
+  constexpr int NI = MT<MODEL>::NI;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int64_t S = t.n_slots;
+  int it = 0;
+  if (gv.n >= 4 && max_iter > 0) {
+    double I[NI], q[6];
+    load_intr<NI>(intr, I);
+    load_pose(pose, S, gv.slot, q);
+    double ch = 1.0;
+    bool go = ch > tol;
+    while (go) {
+      const bool ok = group_pose_gn_step<MODEL, true, G>(gv.base, gv.n, I, q, ch, gv.gl);
+      if (ok) ++it;
+      go = ok && ch > tol && it < max_iter;
+    }
+    if (gv.gl == 0) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pose[c * S + gv.slot] = q[c];
+    }
+  }
+  if (iters && gv.gl == 0) iters[gv.slot] = it;
+}
+
+template <int G>
+struct GroupReduce {
+  template <int M> __device__ __forceinline__ void sum(double* a) const {
+#pragma unroll
+    for (int i = 0; i < M; ++i) a[i] = group_sum<G>(a[i]);
+  }
+};
+
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_pose_init_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                       double* __restrict__ pose, int32_t* __restrict__ status) {
+  constexpr int NI = MT<MODEL>::NI;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int64_t S = t.n_slots;
+  double I[NI];
+  load_intr<NI>(intr, I);
+  double p[6] = {0, 0, 0, 0, 0, 1};
+  const int st = pose_init_walk<MODEL>(gv.base, gv.n, gv.gl, G, I, p, GroupReduce<G>());
+  if (gv.gl == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pose[c * S + gv.slot] = p[c];
+    if (status) status[gv.slot] = gv.n == 0 ? 0 : st;
+  }
+}
+
+// Fused normal-equation evaluation with G lanes per view: each lane accumulates its
+// share of the view's corners, the view blocks are summed over the group, the group's
+// first lane eliminates the pose; one partial record [U|b|cost|C|d] per wavefront.
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                          const double* __restrict__ pose, double lam,
+                                                          double* __restrict__ Vb, double* __restrict__ Wb,
+                                                          double* __restrict__ gb, double* __restrict__ scratch,
+                                                          int scratch_stride, int local) {
+  constexpr int NI = MT<MODEL>::NI;
+  constexpr int NG = IntrAcc<MODEL>::NR;
+  constexpr int NS = trisz(NI) + NI;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double I[NI], p[6], R[9];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, gv.slot, p);
+  rodrigues(p, R);
+  const double tr[3] = {p[3], p[4], p[5]};
+  ViewAcc<MODEL> acc;
+  IntrAcc<MODEL> gacc;
+  acc.zero();
+  gacc.zero();
+  for (int k = gv.gl; k < gv.n; k += G) fused_obs<MODEL, true>(R, tr, I, load_obs<true>(gv.base, k), acc, gacc);
+  if (gv.gl == 0) gacc.add_count(gv.n);
+  const GroupReduce<G> red;
+  red.template sum<21>(acc.V);
+  red.template sum<NI * 6>(acc.W);
+  red.template sum<6>(acc.g);
+  if (!local) {
+    double Jl[9];
+    left_jacobian(p, Jl);
+    to_rodrigues_frame<NI>(Jl, acc.V, acc.W, acc.g);
+  }
+  if (Vb && gv.gl == 0) {
+#pragma unroll
+    for (int e = 0; e < 21; ++e) Vb[e * S + gv.slot] = acc.V[e];
+#pragma unroll
+    for (int e = 0; e < NI * 6; ++e) Wb[e * S + gv.slot] = acc.W[e];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) gb[e * S + gv.slot] = acc.g[e];
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const double s = wave_sum(gacc.v[i]);
+    if (lane == 0) scratch[(size_t)i * scratch_stride + wave] = s;
+  }
+  if (local) return;
+  double sacc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
+  if (gv.gl == 0 && gv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double s = wave_sum(sacc[i]);
+    if (lane == 0) scratch[(size_t)(NG + i) * scratch_stride + wave] = s;
+  }
+}
+
+// Evaluations A and B with G lanes per view (the pinhole LM driver's stages).
+template <int MODEL, int MODE, int G>
+__global__ __launch_bounds__(TPB) void k_intr_normal_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                         const double* __restrict__ pose,
+                                                         double* __restrict__ view_cost, double* __restrict__ Vb,
+                                                         double* __restrict__ gb, double* __restrict__ scratch) {
+  constexpr int NI = MT<MODEL>::NI;
+  constexpr int NR = IntrAcc<MODEL>::NR;
+  constexpr int COST = IntrAcc<MODEL>::COST;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double I[NI], p[6], R[9];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, gv.slot, p);
+  rodrigues(p, R);
+  const double tr[3] = {p[3], p[4], p[5]};
+  IntrAcc<MODEL> acc;
+  acc.zero();
+  double V[21], g[6], vc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 21; ++i) V[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) g[i] = 0.0;
+  for (int k = gv.gl; k < gv.n; k += G)
+    intr_normal_obs<MODEL, MODE, true>(R, tr, I, load_obs<true>(gv.base, k), acc, V, g, vc);
+  if (MODE > 0) { if (gv.gl == 0) acc.add_count(gv.n); }
+  else acc.v[COST] += vc;
+  if (view_cost) {
+    const double s = group_sum<G>(vc);
+    if (gv.gl == 0) view_cost[gv.slot] = s;
+  }
+  if (MODE == 2) {
+    const GroupReduce<G> red;
+    red.template sum<21>(V);
+    red.template sum<6>(g);
+    double Jl[9];
+    left_jacobian(p, Jl);
+    vg_to_rodrigues_frame(Jl, V, g);
+    if (gv.gl == 0) {
+#pragma unroll
+      for (int e = 0; e < 21; ++e) Vb[e * S + gv.slot] = V[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) gb[e * S + gv.slot] = g[e];
+    }
+  }
+  if (MODE > 0) {
+    wave_reduce_store<NR>(acc.v, scratch, wave);
+  } else {
+    const double s = wave_sum(acc.v[COST]);
+    if (lane == 0) scratch[(size_t)COST * MAX_WAVES + wave] = s;
+  }
+}
+
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_cross_schur_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                         const double* __restrict__ pose,
+                                                         const double* __restrict__ Vb, const double* __restrict__ gb,
+                                                         double lam, double* __restrict__ Wb,
+                                                         double* __restrict__ scratch, int scratch_stride) {
+  constexpr int NI = MT<MODEL>::NI;
+  constexpr int NS = trisz(NI) + NI;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double I[NI], p[6], R[9];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, gv.slot, p);
+  rodrigues(p, R);
+  const double tr[3] = {p[3], p[4], p[5]};
+  double W[NI * 6];
+#pragma unroll
+  for (int i = 0; i < NI * 6; ++i) W[i] = 0.0;
+  for (int k = gv.gl; k < gv.n; k += G) cross_block_obs<MODEL, true>(R, tr, I, load_obs<true>(gv.base, k), W);
+  const GroupReduce<G> red;
+  red.template sum<NI * 6>(W);
+  double Jl[9];
+  left_jacobian(p, Jl);
+  w_to_rodrigues_frame<NI>(Jl, W);
+  if (Wb && gv.gl == 0) {
+#pragma unroll
+    for (int e = 0; e < NI * 6; ++e) Wb[e * S + gv.slot] = W[e];
+  }
+  double sacc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
+  if (gv.gl == 0 && gv.n > 0) {
+    double V[21], g[6];
+#pragma unroll
+    for (int e = 0; e < 21; ++e) V[e] = Vb[e * S + gv.slot];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) g[e] = gb[e * S + gv.slot];
+    lane_schur_regs<NI>(V, W, g, lam, sacc);
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const double s = wave_sum(sacc[i]);
+    if (lane == 0) scratch[(size_t)i * scratch_stride + wave] = s;
+  }
 }
 
 template <int MODEL>
@@ -603,13 +844,21 @@ __global__ __launch_bounds__(TPB) void k_backsub(camcal_tiles t, const double* _
   wave_reduce_store<2>(acc, scratch, wave);
 }
 
-// Reduced solve on one lane (see camcal_lane.h: reduced_solve).
-__global__ void k_solve_reduced(int NI, const double* __restrict__ glob, const double* __restrict__ schur,
-                                unsigned mask, double lam, double scale,
-                                const double* __restrict__ intr_in, double* __restrict__ intr_out,
-                                double* __restrict__ dK, double* __restrict__ stats) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  reduced_solve(NI, glob, schur, mask, lam, scale, intr_in, intr_out, dK, stats);
+// Reduced solve on one lane (see camcal_lane.h: reduced_solve); the records and the
+// working matrix are staged in LDS by the whole wavefront first.
+__global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __restrict__ glob,
+                                                      const double* __restrict__ schur, unsigned mask, double lam,
+                                                      double scale, const double* __restrict__ intr_in,
+                                                      double* __restrict__ intr_out, double* __restrict__ dK,
+                                                      double* __restrict__ stats) {
+  __shared__ double s_glob[56], s_schur[56], s_intr[16], s_ws[REDUCED_WS];
+  const int NU = NI * (NI + 1) / 2, lane = threadIdx.x;
+  if (lane < NU + NI + 1) s_glob[lane] = glob[lane];
+  if (lane < NU + NI) s_schur[lane] = schur[lane];
+  if (lane < NI) s_intr[lane] = intr_in[lane];
+  __syncthreads();
+  if (lane != 0) return;
+  reduced_solve(NI, s_glob, s_schur, mask, lam, scale, s_intr, intr_out, dK, stats, s_ws);
 }
 
 __global__ __launch_bounds__(TPB) void k_pack_tiles(const float* __restrict__ obj, const float* __restrict__ img,
@@ -822,11 +1071,31 @@ inline int grid_persistent(const camcal_tiles* t) {
   return g < MAX_WAVES / WPB ? g : MAX_WAVES / WPB;
 }
 
+// Lanes per view for this set: 1 (large sets: a lane walks its view), or 16 / 64 for
+// small planar sets.  The partial records of a grouped launch are one per wavefront
+// (n_tiles * G of them) and must fit the scratch every caller holds (camcal_scratch_len).
+int g_lanes_per_view = -1;                 // camcal_set_lanes_per_view
+constexpr int GROUP64_MAX_TILES = 32;      // <= 2048 views: one wavefront per view
+constexpr int GROUP16_MAX_TILES = 128;     // <= 8192 views: four views per wavefront
+inline int group_lanes(const camcal_tiles* t) {
+  if (!t->planar || g_lanes_per_view == 1) return 1;
+  if (g_lanes_per_view == 64) return t->n_tiles <= GROUP64_MAX_TILES ? 64 : 1;
+  if (g_lanes_per_view == 16) return t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
+  return t->n_tiles <= GROUP64_MAX_TILES ? 64 : t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
+}
+inline int grid_groups(const camcal_tiles* t, int G) { return (int)((t->n_slots * G + TPB - 1) / TPB); }
+
 }  // namespace
 
 extern "C" {
 
 int camcal_version(void) { return 100; }
+
+int camcal_set_lanes_per_view(int lanes) {
+  if (lanes != -1 && lanes != 1 && lanes != 16 && lanes != 64) return CAMCAL_E_BADARG;
+  g_lanes_per_view = lanes;
+  return 0;
+}
 int camcal_n_intr(int model) { return model == CAMCAL_PINHOLE ? 9 : model == CAMCAL_FISHEYE ? 8 : CAMCAL_E_BADMODEL; }
 int camcal_glob_len(int model) {
   const int ni = camcal_n_intr(model);
@@ -887,6 +1156,20 @@ int camcal_pose_init(int model, const camcal_tiles* tiles, const double* intr, d
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose) return CAMCAL_E_BADARG;
   const dim3 g(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int G = group_lanes(tiles);
+  if (G > 1) {
+    const dim3 gg(grid_groups(tiles, G));
+    if (model == CAMCAL_PINHOLE) {
+      if (G == 64) hipLaunchKernelGGL((k_pose_init_grp<PINHOLE, 64>), gg, b, 0, s, *tiles, intr, pose, status);
+      else hipLaunchKernelGGL((k_pose_init_grp<PINHOLE, 16>), gg, b, 0, s, *tiles, intr, pose, status);
+    } else {
+      if (G == 64) hipLaunchKernelGGL((k_pose_init_grp<FISHEYE, 64>), gg, b, 0, s, *tiles, intr, pose, status);
+      else hipLaunchKernelGGL((k_pose_init_grp<FISHEYE, 16>), gg, b, 0, s, *tiles, intr, pose, status);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_pose_init<PINHOLE>, g, b, 0, s, *tiles, intr, pose, status);
   else if (model == CAMCAL_FISHEYE) hipLaunchKernelGGL(k_pose_init<FISHEYE>, g, b, 0, s, *tiles, intr, pose, status);
   else return CAMCAL_E_BADMODEL;
@@ -901,6 +1184,19 @@ int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr,
   const dim3 g(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   const int sl = STRAGGLER_LANES;
+  const int G = group_lanes(tiles);
+  if (G > 1) {
+    const dim3 gg(grid_groups(tiles, G));
+    if (model == CAMCAL_PINHOLE) {
+      if (G == 64) hipLaunchKernelGGL((k_pose_refine_grp<PINHOLE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+      else hipLaunchKernelGGL((k_pose_refine_grp<PINHOLE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+    } else {
+      if (G == 64) hipLaunchKernelGGL((k_pose_refine_grp<FISHEYE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+      else hipLaunchKernelGGL((k_pose_refine_grp<FISHEYE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
 #define LAUNCH(M, P) hipLaunchKernelGGL((k_pose_refine<M, P>), g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, sl)
   DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
 #undef LAUNCH
@@ -915,12 +1211,25 @@ int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
   if ((V == nullptr) != (g == nullptr) || (V && !with_normal)) return CAMCAL_E_BADARG;
   const int len = camcal_glob_len(model);
   if (len < 0) return len;
-  const int gp = grid_persistent(tiles);
-  const dim3 gr(gp), b(TPB);
+  int gp = grid_persistent(tiles);
+  const dim3 b(TPB);
   hipStream_t s = (hipStream_t)stream;
   double* red = scratch + (size_t)MAX_NV * MAX_WAVES;      // reduced values ahead of their expansion
   const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
   const int ci = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::COST : IntrAcc<FISHEYE>::COST;
+  const int G = group_lanes(tiles);
+  if (G > 1) {
+    gp = grid_groups(tiles, G);                             // one partial per wavefront, <= MAX_WAVES of them
+    const dim3 gg(gp);
+    const int mode = (with_normal && V) ? 2 : with_normal ? 1 : 0;
+#define LAUNCHG(M, MODE, GG) hipLaunchKernelGGL((k_intr_normal_grp<M, MODE, GG>), gg, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
+#define LAUNCHGM(M, GG) do { if (mode == 2) LAUNCHG(M, 2, GG); else if (mode == 1) LAUNCHG(M, 1, GG); else LAUNCHG(M, 0, GG); } while (0)
+    if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHGM(PINHOLE, 64); else LAUNCHGM(PINHOLE, 16); }
+    else { if (G == 64) LAUNCHGM(FISHEYE, 64); else LAUNCHGM(FISHEYE, 16); }
+#undef LAUNCHGM
+#undef LAUNCHG
+  } else {
+  const dim3 gr(gp);
 #define LAUNCH2(M, P) hipLaunchKernelGGL((k_intr_normal<M, 2, P>), gr, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
 #define LAUNCH1(M, P) hipLaunchKernelGGL((k_intr_normal<M, 1, P>), gr, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
 #define LAUNCH0(M, P) hipLaunchKernelGGL((k_intr_normal<M, 0, P>), gr, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
@@ -930,6 +1239,7 @@ int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
 #undef LAUNCH0
 #undef LAUNCH1
 #undef LAUNCH2
+  }
   HIP_TRY(hipGetLastError());
   if (with_normal) hipLaunchKernelGGL(k_finalize, dim3(nr), dim3(TPB), 0, s, scratch, gp * WPB, red);
   else hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)ci * MAX_WAVES, gp * WPB, red + ci);
@@ -949,6 +1259,19 @@ int camcal_cross_schur(int model, const camcal_tiles* tiles, const double* intr,
   const dim3 gr(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   const int nt = tiles->n_tiles;
+  const int G = group_lanes(tiles);
+  if (G > 1) {
+    const int np = nt * G;
+    const dim3 gg(grid_groups(tiles, G));
+#define LAUNCHG(M, GG) hipLaunchKernelGGL((k_cross_schur_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, np)
+    if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHG(PINHOLE, 64); else LAUNCHG(PINHOLE, 16); }
+    else { if (G == 64) LAUNCHG(FISHEYE, 64); else LAUNCHG(FISHEYE, 16); }
+#undef LAUNCHG
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_strided, dim3(ns), dim3(TPB), 0, s, scratch, np, np, schur);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
 #define LAUNCHS(M, P) hipLaunchKernelGGL((k_cross_schur<M, true, P>), gr, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, nt)
 #define LAUNCHN(M, P) hipLaunchKernelGGL((k_cross_schur<M, false, P>), gr, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, nt)
   if (W_out) DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCHS);
@@ -1040,6 +1363,23 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
   hipStream_t s = (hipStream_t)stream;
   const int nt = tiles->n_tiles;
   const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
+  const int G = group_lanes(tiles);
+  if (G > 1) {
+    const int np = nt * G;                              // one partial record per wavefront
+    const dim3 gg(grid_groups(tiles, G));
+    double* redg = scratch + (size_t)(nr + ns) * np;
+#define LAUNCHG(M, GG) hipLaunchKernelGGL((k_normal_fused_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, np, 0)
+    if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHG(PINHOLE, 64); else LAUNCHG(PINHOLE, 16); }
+    else { if (G == 64) LAUNCHG(FISHEYE, 64); else LAUNCHG(FISHEYE, 16); }
+#undef LAUNCHG
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_strided, dim3(nr + ns), dim3(TPB), 0, s, scratch, np, np, redg);
+    HIP_TRY(hipGetLastError());
+    if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, redg, glob, ns, 0);
+    else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, redg, glob, ns, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   double* red = scratch + (size_t)(nr + ns) * nt;
   if (wb) {
 #define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt)

@@ -66,6 +66,18 @@ CC_HD void lane_view_blocks(const LaneTile& tv, const double* intr, const double
 // K1+K2 fused: one pass over the view's corners feeding both accumulator sets
 // (projection and Jacobian evaluated once per observation).
 // LOCAL: leave the blocks in the local tangent frame of the pose (rig solver).
+template <int MODEL, bool PLANAR>
+CC_HD void fused_obs(const double R[9], const double t[3], const double* intr, const Obs& o,
+                     ViewAcc<MODEL>& acc, IntrAcc<MODEL>& gacc) {
+  double Yr[3], Yc[3];
+  transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+  PointEval<MODEL> p;
+  eval_point<true>(Yc, intr, p);
+  const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
+  accumulate_intr(gacc, p, eu, ev);
+  accumulate_view(acc, p, Yr, eu, ev);
+}
+
 template <int MODEL, bool PLANAR, bool LOCAL = false>
 CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const double pose[6],
                              ViewAcc<MODEL>& acc, IntrAcc<MODEL>& gacc) {
@@ -73,15 +85,7 @@ CC_HD void lane_normal_fused(const LaneTile& tv, const double* intr, const doubl
   rodrigues(pose, R);
   const double t[3] = {pose[3], pose[4], pose[5]};
   acc.zero();
-  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
-    double Yr[3], Yc[3];
-    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
-    PointEval<MODEL> p;
-    eval_point<true>(Yc, intr, p);
-    const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
-    accumulate_intr(gacc, p, eu, ev);
-    accumulate_view(acc, p, Yr, eu, ev);
-  });
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) { fused_obs<MODEL, PLANAR>(R, t, intr, o, acc, gacc); });
   gacc.add_count(tv.n);
   if (!LOCAL) {
     double Jl[9];
@@ -121,6 +125,25 @@ CC_HD void lane_schur_regs(double V[21], double* W, double g[6], double lam, dou
 // MODE 0: cost only; 1: U, b, cost; 2: U, b, cost, V, g.  Returns the lane's
 // own view cost (sum of squared residuals).
 template <int MODEL, int MODE, bool PLANAR>
+CC_HD void intr_normal_obs(const double R[9], const double t[3], const double* intr, const Obs& o,
+                           IntrAcc<MODEL>& acc, double* V, double* g, double& vc) {
+  double Yr[3], Yc[3];
+  transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+  PointEval<MODEL> p;
+  eval_point<(MODE > 0)>(Yc, intr, p);
+  const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
+  if (MODE > 0) accumulate_intr(acc, p, eu, ev);
+  if (MODE == 2) {
+    double ju[6], jv[6];
+    pose_row(Yr, p.gu, ju);
+    pose_row(Yr, p.gv, jv);
+    accumulate_vg(V, g, ju, jv, eu, ev);
+  }
+  vc = fma(eu, eu, vc);
+  vc = fma(ev, ev, vc);
+}
+
+template <int MODEL, int MODE, bool PLANAR>
 CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const double pose[6],
                               IntrAcc<MODEL>& acc, double* V, double* g) {
   double R[9];
@@ -133,22 +156,7 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
     CC_UNROLL
     for (int i = 0; i < 6; ++i) g[i] = 0.0;
   }
-  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
-    double Yr[3], Yc[3];
-    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
-    PointEval<MODEL> p;
-    eval_point<(MODE > 0)>(Yc, intr, p);
-    const double eu = p.pu - (double)o.u, ev = p.pv - (double)o.v;
-    if (MODE > 0) accumulate_intr(acc, p, eu, ev);
-    if (MODE == 2) {
-      double ju[6], jv[6];
-      pose_row(Yr, p.gu, ju);
-      pose_row(Yr, p.gv, jv);
-      accumulate_vg(V, g, ju, jv, eu, ev);
-    }
-    vc = fma(eu, eu, vc);
-    vc = fma(ev, ev, vc);
-  });
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) { intr_normal_obs<MODEL, MODE, PLANAR>(R, t, intr, o, acc, V, g, vc); });
   if (MODE > 0) acc.add_count(tv.n);
   else acc.v[IntrAcc<MODEL>::COST] += vc;
   if (MODE == 2) {
@@ -161,6 +169,18 @@ CC_HD double lane_intr_normal(const LaneTile& tv, const double* intr, const doub
 
 // Evaluation B: the view's cross block W = Ji^T Je (Rodrigues frame).
 template <int MODEL, bool PLANAR>
+CC_HD void cross_block_obs(const double R[9], const double t[3], const double* intr, const Obs& o, double* W) {
+  double Yr[3], Yc[3];
+  transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
+  PointEval<MODEL> p;
+  eval_point<true>(Yc, intr, p);
+  double ju[6], jv[6];
+  pose_row(Yr, p.gu, ju);
+  pose_row(Yr, p.gv, jv);
+  accumulate_w(W, p, ju, jv);
+}
+
+template <int MODEL, bool PLANAR>
 CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double pose[6], double* W) {
   constexpr int NI = MT<MODEL>::NI;
   double R[9];
@@ -168,16 +188,7 @@ CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double
   const double t[3] = {pose[3], pose[4], pose[5]};
   CC_UNROLL
   for (int i = 0; i < NI * 6; ++i) W[i] = 0.0;
-  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
-    double Yr[3], Yc[3];
-    transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
-    PointEval<MODEL> p;
-    eval_point<true>(Yc, intr, p);
-    double ju[6], jv[6];
-    pose_row(Yr, p.gu, ju);
-    pose_row(Yr, p.gv, jv);
-    accumulate_w(W, p, ju, jv);
-  });
+  for_each_obs<PLANAR>(tv, [&](const Obs& o) { cross_block_obs<MODEL, PLANAR>(R, t, intr, o, W); });
   double Jl[9];
   left_jacobian(pose, Jl);
   w_to_rodrigues_frame<NI>(Jl, W);
@@ -433,16 +444,26 @@ CC_HD void rot_to_rvec(const double R[9], double r[3]) {
 // undistort -> homography (normalised DLT, then Gauss-Newton on the transfer
 // error, <= 10 steps) -> (u1, u2 - (u1.u2)u1, u1 x u2) -> Rodrigues vector,
 // t = h3 / sc - R [mx my 0]^T.  Returns 0 on success.
-template <int MODEL>
-CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6]) {
-  const int n = tv.n;
+// The corners k0, k0 + step, ... of the view are walked by this lane; red.sum<M>(a) makes
+// the M sums in a[] complete (nothing to do when one lane walks the whole view, a
+// butterfly over the lanes that share the view otherwise -- every lane then holds the
+// same sums).
+struct NoReduce {
+  template <int M> CC_HD void sum(double*) const {}
+};
+
+template <int MODEL, class Red>
+CC_HD int pose_init_walk(const float* base, int n, int k0, int step, const double* intr, double pose[6],
+                         const Red& red) {
   if (n < 4) return 1;
   // pass 1: centroid / spread of the board points
-  double sx = 0, sy = 0, sxx = 0, syy = 0;
-  for (int k = 0; k < n; ++k) {
-    const Obs o = load_obs<true>(tv.base, k);
-    sx += o.X; sy += o.Y; sxx += (double)o.X * o.X; syy += (double)o.Y * o.Y;
+  double m4[4] = {0, 0, 0, 0};
+  for (int k = k0; k < n; k += step) {
+    const Obs o = load_obs<true>(base, k);
+    m4[0] += o.X; m4[1] += o.Y; m4[2] += (double)o.X * o.X; m4[3] += (double)o.Y * o.Y;
   }
+  red.template sum<4>(m4);
+  const double sx = m4[0], sy = m4[1], sxx = m4[2], syy = m4[3];
   const double inv_n = 1.0 / n;
   const double mX = sx * inv_n, mY = sy * inv_n;
   double dX = sqrt(fmax(sxx * inv_n - mX * mX, 0.0)), dY = sqrt(fmax(syy * inv_n - mY * mY, 0.0));
@@ -453,8 +474,8 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
   for (int i = 0; i < 36; ++i) A[i] = 0.0;
   CC_UNROLL
   for (int i = 0; i < 8; ++i) b[i] = 0.0;
-  for (int k = 0; k < n; ++k) {
-    const Obs o = load_obs<true>(tv.base, k);
+  for (int k = k0; k < n; k += step) {
+    const Obs o = load_obs<true>(base, k);
     double x, y;
     undistort_px<MODEL>(o.u, o.v, intr, x, y);
     const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
@@ -468,6 +489,8 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
       b[i] += r0[i] * x + r1[i] * y;
     }
   }
+  red.template sum<36>(A);
+  red.template sum<8>(b);
   if (!chol_solve<8>(A, b)) return 2;
   double h[8];
   CC_UNROLL
@@ -478,8 +501,8 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
     for (int i = 0; i < 36; ++i) A[i] = 0.0;
     CC_UNROLL
     for (int i = 0; i < 8; ++i) b[i] = 0.0;
-    for (int k = 0; k < n; ++k) {
-      const Obs o = load_obs<true>(tv.base, k);
+    for (int k = k0; k < n; k += step) {
+      const Obs o = load_obs<true>(base, k);
       double x, y;
       undistort_px<MODEL>(o.u, o.v, intr, x, y);
       const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
@@ -496,6 +519,8 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
         b[i] += r0[i] * ex + r1[i] * ey;
       }
     }
+    red.template sum<36>(A);
+    red.template sum<8>(b);
     if (!chol_solve<8>(A, b)) break;
     double dmax = 0.0, hmax = 0.0;
     CC_UNROLL
@@ -529,29 +554,39 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
   return 0;
 }
 
+template <int MODEL>
+CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6]) {
+  return pose_init_walk<MODEL>(tv.base, tv.n, 0, 1, intr, pose, NoReduce());
+}
+
 // ---------------------------------------------------------------------------
 // Reduced solve (U' - C) dK = b - d on the free intrinsics: symmetric Jacobi
 // scaling + Gaussian elimination with partial pivoting (single lane; NI <= 9).
 // glob = [U | b | cost], schur = [C | d]; intr_out = intr_in + scale * dK.
 // The eliminated form of CvLevMarq::step / fisheye::calibrate's solve(JJ2, ex3).
+// ws: REDUCED_WS doubles of working storage (the kernel passes LDS: the pivoting makes
+// every index dynamic, and private arrays indexed dynamically live in scratch memory).
+constexpr int REDUCED_WS = 128;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
 inline void reduced_solve(int NI, const double* glob, const double* schur, unsigned mask, double lam,
                           double scale, const double* intr_in, double* intr_out, double* dK,
-                          double* stats) {
+                          double* stats, double* ws) {
   const int NU = NI * (NI + 1) / 2;
-  double A[9 * 10];
-  int idx[9];
+  double* A = ws;            // 9 x 10
+  double* sc = ws + 90;      // 9
+  double* x = ws + 99;       // 9
+  double* d = ws + 108;      // 9
+  int* idx = (int*)(ws + 117);
   int nf = 0;
   for (int a = 0; a < NI; ++a)
     if (mask & (1u << a)) idx[nf++] = a;
   auto tr = [NI](int i, int j) { return i <= j ? i * NI - (i * (i - 1)) / 2 + (j - i) : j * NI - (j * (j - 1)) / 2 + (i - j); };
-  double sc[9];
   for (int i = 0; i < nf; ++i) {
     const int a = idx[i];
-    const double d = glob[tr(a, a)] * (1.0 + lam) - schur[tr(a, a)];
-    sc[i] = d > 0.0 ? 1.0 / sqrt(d) : 1.0;
+    const double dd = glob[tr(a, a)] * (1.0 + lam) - schur[tr(a, a)];
+    sc[i] = dd > 0.0 ? 1.0 / sqrt(dd) : 1.0;
   }
   for (int i = 0; i < nf; ++i) {
     const int a = idx[i];
@@ -581,13 +616,11 @@ inline void reduced_solve(int NI, const double* glob, const double* schur, unsig
       }
     }
   }
-  double x[9];
   for (int c = nf - 1; c >= 0; --c) {
     double s = A[c * 10 + 9];
     for (int k = c + 1; k < nf; ++k) s -= A[c * 10 + k] * x[k];
     x[c] = A[c * 10 + c] != 0.0 ? s / A[c * 10 + c] : 0.0;
   }
-  double d[9];
   for (int a = 0; a < NI; ++a) d[a] = 0.0;
   for (int i = 0; i < nf; ++i) d[idx[i]] = x[i] * sc[i];
   double s0 = 0, s1 = 0, s2 = 0, s3 = 0;

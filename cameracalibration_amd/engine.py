@@ -84,8 +84,13 @@ class Engine:
                                 self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
                                 lay["n_tiles"], S, 0)
         # pack on the device
-        t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
-        self.tiles.planar = 1 if bool((t_obj[:, 2] == 0).all().item()) else 0
+        if isinstance(obj, np.ndarray):                     # host arrays: no device round trip for the flag
+            planar = not np.asarray(obj).reshape(-1, 3)[:, 2].any()
+            t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+        else:
+            t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+            planar = bool((t_obj[:, 2] == 0).all().item())
+        self.tiles.planar = 1 if planar else 0
         t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
         if t_obj.shape[0] != self.n_obs or t_img.shape[0] != self.n_obs:
             raise ValueError("view_ptr does not match the point arrays")
@@ -94,25 +99,36 @@ class Engine:
                    self.t_slot_view.data_ptr(), C.byref(self.tiles), self.t_pts.data_ptr(), self._stream())
         self._sync()
         del t_obj, t_img, t_vp
-        # solver buffers
-        self.intr = [torch.zeros(16, **f64), torch.zeros(16, **f64)]
-        self.pose = [torch.zeros(6, S, **f64), torch.zeros(6, S, **f64)]
+        # solver buffers: one zeroed allocation, carved up (every piece a multiple of 8 bytes)
+        NI = self.NI
+        sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
+                     W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, dK=16, stats=8,
+                     norms=2, view_cost=S)
+        pool = torch.zeros(sum(sizes.values()), **f64)
+        part, off = {}, 0
+        for k, n_k in sizes.items():
+            part[k] = pool[off:off + n_k]
+            off += n_k
+        self._pool = pool
+        self.intr = [part["intr0"], part["intr1"]]
+        self.pose = [part["pose0"].view(6, S), part["pose1"].view(6, S)]
         self.pose[0][5] = 1.0
         self.pose[1][5] = 1.0
         # pose blocks are double-buffered (current / trial point), W is not
-        self.Vs = [torch.zeros(21, S, **f64), torch.zeros(21, S, **f64)]
-        self.gs = [torch.zeros(6, S, **f64), torch.zeros(6, S, **f64)]
-        self.W = torch.zeros(self.NI * 6, S, **f64)
+        self.Vs = [part["V0"].view(21, S), part["V1"].view(21, S)]
+        self.gs = [part["g0"].view(6, S), part["g1"].view(6, S)]
+        self.W = part["W"].view(NI * 6, S)
         # [U|b|cost] and [C|d] of buffer 0 share one allocation so a full
         # normal-equation evaluation needs a single all-reduce (self.rec)
-        self.rec = torch.zeros(self.glob_len + self.schur_len, **f64)
-        self.glob = [self.rec[:self.glob_len], torch.zeros(self.glob_len, **f64)]
+        self.rec = part["rec"]
+        self.glob = [self.rec[:self.glob_len], part["glob1"]]
         self.schur = self.rec[self.glob_len:]
-        self.dK = torch.zeros(16, **f64)
-        self.stats = torch.zeros(8, **f64)
-        self.norms = torch.zeros(2, **f64)
-        self.view_cost = torch.zeros(S, **f64)
-        self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model, lay["n_tiles"])), **f64)
+        self.dK = part["dK"]
+        self.stats = part["stats"]
+        self.norms = part["norms"]
+        self.view_cost = part["view_cost"]
+        # partial sums: every entry a launch reads was written by that launch
+        self.scratch = torch.empty(int(self.lib.camcal_scratch_len(self.model, lay["n_tiles"])), **f64)
         self.status = torch.zeros(S, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(S, dtype=torch.int32, device=dev)
 

@@ -61,6 +61,15 @@ typedef struct camcal_tiles {
 /* Library version (major*10000 + minor*100 + patch). */
 int camcal_version(void);
 
+/* How many lanes share one view in the per-view kernels.  -1 (the default) chooses by
+ * the size of the set: one lane per view for large sets (the throughput mapping), 16 or
+ * 64 lanes per view for small planar sets (<= 8192 / <= 2048 views), so that a
+ * production-sized call (20 ... 500 views, intrinsicCalib.py:102-105) spreads over the
+ * whole device instead of a handful of wavefronts.  1, 16 or 64 force a mapping where
+ * the set allows it (tests, measurements).  Process-wide, not thread-safe; results
+ * differ between mappings only by the order of the sums.  No reference counterpart. */
+int camcal_set_lanes_per_view(int lanes);
+
 /* Number of doubles in the global normal-equation record of a model:
  *   [ U (NI(NI+1)/2) | b (NI) | cost ]  ->  camcal_glob_len
  *   [ C (NI(NI+1)/2) | d (NI) ]         ->  camcal_schur_len                  */

@@ -257,6 +257,11 @@ void rig_backsub(int n_cams, int64_t P, const double* Vp, const double* gp, cons
 
 extern "C" {
 int camcal_version(void) { return -100; }   // negative: emulator
+
+// the emulator always walks one view per lane; the setting is validated and ignored
+int camcal_set_lanes_per_view(int lanes) {
+  return (lanes == -1 || lanes == 1 || lanes == 16 || lanes == 64) ? 0 : CAMCAL_E_BADARG;
+}
 int camcal_n_intr(int model) { return model == 0 ? 9 : model == 1 ? 8 : CAMCAL_E_BADMODEL; }
 int camcal_glob_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni + 1; }
 int camcal_schur_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni; }
@@ -382,7 +387,8 @@ int camcal_solve_reduced(int model, const double* glob, const double* schur, con
   if (ni < 0) return ni;
   unsigned mask = 0;
   for (int a = 0; a < ni; ++a) if (mask_host[a]) mask |= 1u << a;
-  reduced_solve(ni, glob, schur, mask, lam, scale, intr_in, intr_out, dK, stats);
+  double ws[REDUCED_WS];
+  reduced_solve(ni, glob, schur, mask, lam, scale, intr_in, intr_out, dK, stats, ws);
   return 0;
 }
 int camcal_rig_compose(const camcal_tiles* t, const int32_t* slot_pose, const double* rig_pose, int64_t P,
