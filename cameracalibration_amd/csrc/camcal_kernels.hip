@@ -1446,6 +1446,23 @@ int camcal_rig_local_blocks(int model, const camcal_tiles* tiles, const double* 
   hipStream_t s = (hipStream_t)stream;
   const int nt = tiles->n_tiles;
   const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
+  const int G = group_lanes(tiles);
+  if (G > 1) {
+    const int np = nt * G;
+    const dim3 gg(grid_groups(tiles, G));
+    double* redg = scratch + (size_t)nr * np;
+#define LAUNCHG(M, GG) hipLaunchKernelGGL((k_normal_fused_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, 0.0, V, W, g, scratch, np, 1)
+    if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHG(PINHOLE, 64); else LAUNCHG(PINHOLE, 16); }
+    else { if (G == 64) LAUNCHG(FISHEYE, 64); else LAUNCHG(FISHEYE, 16); }
+#undef LAUNCHG
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_finalize_strided, dim3(nr), dim3(TPB), 0, s, scratch, np, np, redg);
+    HIP_TRY(hipGetLastError());
+    if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, redg, glob, 0, 0);
+    else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, redg, glob, 0, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   double* red = scratch + (size_t)nr * nt;
 #define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P, true>), gr, b, 0, s, *tiles, intr, pose, 0.0, V, W, g, scratch, nt)
   DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);

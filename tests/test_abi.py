@@ -38,6 +38,14 @@ def test_query_entry_points_need_no_gpu():
     assert lib.camcal_scratch_len(1, 100) >= 64 * 64 and lib.camcal_scratch_len(1, 20000) >= 89 * 20000
 
 
+def test_lanes_per_view_setting_is_validated(emu):
+    for lib in (_lib.load(), emu):
+        for ok in (1, 16, 64, -1):
+            assert lib.camcal_set_lanes_per_view(ok) == 0
+        for bad in (0, 2, 32, 128, -2):
+            assert lib.camcal_set_lanes_per_view(bad) < 0
+
+
 def test_emulator_exports_the_same_abi(emu):
     for n in _declared():
         assert hasattr(emu.dll, n), n

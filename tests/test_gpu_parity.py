@@ -32,6 +32,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[1, 16, 64], ids=["lane-per-view", "16-lanes-per-view", "64-lanes-per-view"])
+def mapping(request, dev):
+    """Run a small-set test under each mapping of views to lanes (include/camcal.h:
+    camcal_set_lanes_per_view); the default (-1, chosen by size) is restored afterwards."""
+    lib = _lib.load()
+    lib.check(lib.camcal_set_lanes_per_view(request.param), "camcal_set_lanes_per_view")
+    yield request.param
+    lib.check(lib.camcal_set_lanes_per_view(-1), "camcal_set_lanes_per_view")
+
+
 def sym(tri, n):
     U = np.zeros((n, n))
     U[np.triu_indices(n)] = tri
@@ -44,7 +54,7 @@ def rel(a, b):
 
 @pytest.mark.parametrize("name,model,mid,nv", [("C1", "pinhole", 0, 20), ("C2", "fisheye", 1, 500),
                                                ("C3", "fisheye", 1, 700), ("C3", "fisheye", 1, 1)])
-def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv):
+def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv, mapping):
     P = synth.config(name, n_views=nv)
     objs, imgs = P.as_lists()
     views = O.Views(objs, imgs)
@@ -86,7 +96,7 @@ def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv):
         assert abs(nr[1] / (poses ** 2).sum() - 1) < 1e-12
 
 
-def test_cost_only_and_per_view_cost(dev):
+def test_cost_only_and_per_view_cost(dev, mapping):
     P = synth.config("C3", n_views=300)
     objs, imgs = P.as_lists()
     views = O.Views(objs, imgs)
@@ -101,7 +111,7 @@ def test_cost_only_and_per_view_cost(dev):
     assert np.allclose(np.sqrt(vc) / views.n, want, rtol=1e-11)
 
 
-def test_pose_init_and_refine_match_oracle(dev):
+def test_pose_init_and_refine_match_oracle(dev, mapping):
     P = synth.config("C2", n_views=200)
     objs, imgs = P.as_lists()
     views = O.Views(objs, imgs)
@@ -120,7 +130,7 @@ def test_pose_init_and_refine_match_oracle(dev):
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
-def test_golden_vectors_through_drop_in_api(dev, path):
+def test_golden_vectors_through_drop_in_api(dev, path, mapping):
     from tests.test_golden import check, load
     z, objs, imgs, crit = load(path)
     size = tuple(int(v) for v in z["image_size"])
@@ -134,7 +144,7 @@ def test_golden_vectors_through_drop_in_api(dev, path):
     check(z, r, info["iters"])
 
 
-def test_config1_pinhole_vs_oracle(dev):
+def test_config1_pinhole_vs_oracle(dev, mapping):
     P = synth.config("C1")
     objs, imgs = P.as_lists()
     K, D = P.K_guess.copy(), P.D_guess.copy()
@@ -144,7 +154,7 @@ def test_config1_pinhole_vs_oracle(dev):
     assert np.allclose(K, o[1], rtol=1e-8) and np.allclose(D, o[2], rtol=1e-6, atol=1e-10)
 
 
-def test_config2_fisheye_500_views_vs_oracle(dev):
+def test_config2_fisheye_500_views_vs_oracle(dev, mapping):
     P = synth.config("C2")
     objs, imgs = P.as_lists()
     info = {}
@@ -158,7 +168,7 @@ def test_config2_fisheye_500_views_vs_oracle(dev):
     assert np.allclose(r[1][[0, 1, 0, 1], [0, 1, 2, 2]], P.K_true, rtol=2e-3)
 
 
-def test_config3_ragged_subsample_vs_oracle(dev):
+def test_config3_ragged_subsample_vs_oracle(dev, mapping):
     P = synth.config("C3", n_views=2000)
     objs, imgs = P.as_lists()
     r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE, criteria=CRIT)
