@@ -87,10 +87,11 @@ def big_solve(name, n_views, dev, lib):
             "includes packing, pose initialisation and every host round trip"}
 
 
-def solve_times(dev):
+def solve_times(dev, with_cpu=True):
     """Wall-clock of whole solves through the drop-in API (SURVEY.md 8d asks for it
     next to the evaluation rate): median of 3 after one warm-up, host lists in,
-    results out, so H2D, launches and every host round trip are inside."""
+    results out, so H2D, launches and every host round trip are inside.  with_cpu:
+    the same C1 / C2 calls through the numpy oracle (one host thread) beside them."""
     import cameracalibration_amd as cc
     from cameracalibration_amd import rig
     out = {}
@@ -119,6 +120,12 @@ def solve_times(dev):
             return info
         ms, info = med(c1)
         out["C1_pinhole_20x54"] = {"ms": ms, "iterations": info["iters"]}
+        if with_cpu:
+            from oracle import cvcalib as O
+            t0 = time.perf_counter()
+            O.calibrate_camera(o, i, P.image_size, P.K_guess, P.D_guess, flags=1, criteria=crit, solver="dense")
+            out["C1_pinhole_20x54"]["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+            out["C1_pinhole_20x54"]["cpu_oracle"] = "oracle/cvcalib.py dense CvLevMarq (cv2's formulation), numpy, 1 thread"
         P2 = synth.config("C2")
         o2, i2 = P2.as_lists()
 
@@ -129,6 +136,12 @@ def solve_times(dev):
             return info
         ms, info = med(c2)
         out["C2_fisheye_500x88"] = {"ms": ms, "iterations": info["iters"]}
+        if with_cpu:
+            t0 = time.perf_counter()
+            O.fisheye_calibrate(o2, i2, P2.image_size, P2.K_guess, P2.D_guess, flags=fe, criteria=crit, solver="schur")
+            out["C2_fisheye_500x88"]["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+            out["C2_fisheye_500x88"]["cpu_oracle"] = ("oracle/cvcalib.py Schur-eliminated Gauss-Newton, numpy, 1 thread (cv2's dense "
+                                                      "formulation of the same loop needs a 3008 x 3008 J^T J per iteration)")
         R = synth.config("C4", device=dev)
         cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c])
                 for c in range(R.n_cams)]
@@ -273,7 +286,7 @@ def main():
         if world == 1 and not args.no_solves:
             del E
             torch.cuda.empty_cache()
-            out["solve_wall_clock"] = solve_times(dev)
+            out["solve_wall_clock"] = solve_times(dev, with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
