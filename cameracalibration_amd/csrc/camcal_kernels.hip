@@ -47,14 +47,73 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
-template <int NV>
-__device__ __forceinline__ void wave_reduce_store(const double* v, double* scratch, int wave_id) {
-  const int lane = threadIdx.x & 63;
+
+// Sum N per-lane values over the wavefront with N + N/2 + ... exchanges instead of the 6 N of
+// a butterfly per value: at each step a lane keeps one value of every pair and hands the
+// other to its partner (xor OFF), so the number of live values halves while the number of
+// lanes summed doubles.  Afterwards lane l holds, in v[i], the wavefront total of value
+// 64 i + bitreverse6(l); wave_scatter_store writes them out.
+template <int N, int OFF>
+struct WaveReduceScatter {
+  static __device__ __forceinline__ void run(double* v, int lane) {
+    constexpr int H = (N + 1) / 2;
+    const bool up = (lane & OFF) != 0;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const double s = wave_sum(v[i]);
-    if (lane == 0) scratch[(size_t)i * MAX_WAVES + wave_id] = s;
+    for (int i = 0; i < H; ++i) {
+      const double a = v[2 * i], b = (2 * i + 1 < N) ? v[2 * i + 1] : 0.0;
+      const double send = up ? a : b, keep = up ? b : a;
+      v[i] = keep + __shfl_xor(send, OFF, 64);
+    }
+    WaveReduceScatter<H, OFF / 2>::run(v, lane);
   }
+};
+template <int N>
+struct WaveReduceScatter<N, 0> {
+  static __device__ __forceinline__ void run(double*, int) {}
+};
+
+// All-reduce of N per-lane values over groups of 2 OFF lanes: the halving steps above
+// down to one owner per value, then the same exchanges backwards so that every lane of
+// the group ends with every total (bitwise the same in all of them).
+template <int N, int OFF>
+struct GroupAllReduce {
+  static __device__ __forceinline__ void run(double* v, int lane) {
+    constexpr int H = (N + 1) / 2;
+    const bool up = (lane & OFF) != 0;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const double a = v[2 * i], b = (2 * i + 1 < N) ? v[2 * i + 1] : 0.0;
+      const double send = up ? a : b, keep = up ? b : a;
+      v[i] = keep + __shfl_xor(send, OFF, 64);
+    }
+    GroupAllReduce<H, OFF / 2>::run(v, lane);
+#pragma unroll
+    for (int i = H - 1; i >= 0; --i) {
+      const double own = v[i], got = __shfl_xor(own, OFF, 64);
+      if (2 * i + 1 < N) v[2 * i + 1] = up ? own : got;
+      v[2 * i] = up ? got : own;
+    }
+  }
+};
+template <int N>
+struct GroupAllReduce<N, 0> {
+  static __device__ __forceinline__ void run(double*, int) {}
+};
+
+template <int N>
+__device__ __forceinline__ void wave_scatter_store(double* v, int lane, double* __restrict__ dst, size_t stride) {
+  WaveReduceScatter<N, 32>::run(v, lane);
+  const int r = (int)(__brev((unsigned)lane) >> 26);
+#pragma unroll
+  for (int i = 0; i < (N + 63) / 64; ++i) {
+    const int idx = 64 * i + r;
+    if (idx < N) dst[(size_t)idx * stride] = v[i];
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void wave_reduce_store(double* v, double* scratch, int wave_id) {
+  wave_scatter_store<NV>(v, threadIdx.x & 63, scratch + wave_id, MAX_WAVES);
 }
 
 // second stage: out[i] = sum_w scratch[i][w], fixed order
@@ -199,11 +258,7 @@ __global__ __launch_bounds__(TPB) void k_cross_schur(camcal_tiles t, const doubl
     for (int e = 0; e < 6; ++e) g[e] = gb[e * S + slot];
     lane_schur_regs<NI>(V, W, g, lam, sacc);
   }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const double s = wave_sum(sacc[i]);
-    if (lane == 0) scratch[(size_t)i * scratch_stride + tile] = s;
-  }
+  wave_scatter_store<NS>(sacc, lane, scratch + tile, scratch_stride);
 }
 
 // Fused normal-equation evaluation: U, b, cost + per-view blocks + Schur
@@ -229,7 +284,14 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   ViewAcc<MODEL> acc;
   IntrAcc<MODEL> gacc;
   gacc.zero();
-  lane_normal_fused<MODEL, PLANAR, LOCAL>(tv, I, p, acc, gacc);
+  lane_normal_fused<MODEL, PLANAR, true>(tv, I, p, acc, gacc);       // sums in the local tangent frame
+  // C = W V^-1 W^T and d = W V^-1 g do not depend on the pose parametrisation, so the map to
+  // Rodrigues coordinates is only needed for stored blocks and for the damping of diag(V)
+  if (!LOCAL && (WRITE_BLOCKS || lam != 0.0)) {
+    double Jl[9];
+    left_jacobian(p, Jl);
+    to_rodrigues_frame<NI>(Jl, acc.V, acc.W, acc.g);
+  }
   if (WRITE_BLOCKS) {
 #pragma unroll
     for (int e = 0; e < 21; ++e) Vb[e * S + slot] = acc.V[e];
@@ -238,21 +300,13 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
 #pragma unroll
     for (int e = 0; e < 6; ++e) gb[e * S + slot] = acc.g[e];
   }
-#pragma unroll
-  for (int i = 0; i < NG; ++i) {
-    const double s = wave_sum(gacc.v[i]);
-    if (lane == 0) scratch[(size_t)i * scratch_stride + tile] = s;
-  }
+  wave_scatter_store<NG>(gacc.v, lane, scratch + tile, scratch_stride);
   if (LOCAL) return;                      // rig solver: elimination happens per board pose
   double sacc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
   if (tv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const double s = wave_sum(sacc[i]);
-    if (lane == 0) scratch[(size_t)(NG + i) * scratch_stride + tile] = s;
-  }
+  wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + tile, scratch_stride);
 }
 
 // ---------------------------------------------------------------------------
@@ -452,10 +506,8 @@ __device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, con
     pose_row(Yr, p.gv, jv);
     accumulate_vg(V, g, ju, jv, eu, ev);
   }
-#pragma unroll
-  for (int i = 0; i < 21; ++i) V[i] = group_sum<G>(V[i]);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) g[i] = group_sum<G>(g[i]);
+  GroupAllReduce<21, G / 2>::run(V, threadIdx.x & 63);
+  GroupAllReduce<6, G / 2>::run(g, threadIdx.x & 63);
   return pose_gn_update(V, g, pose, change);       // every lane of the group holds the same sums
 }
 
@@ -584,8 +636,7 @@ __global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const d
 template <int G>
 struct GroupReduce {
   template <int M> __device__ __forceinline__ void sum(double* a) const {
-#pragma unroll
-    for (int i = 0; i < M; ++i) a[i] = group_sum<G>(a[i]);
+    GroupAllReduce<M, G / 2>::run(a, threadIdx.x & 63);
   }
 };
 
@@ -639,7 +690,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
   red.template sum<21>(acc.V);
   red.template sum<NI * 6>(acc.W);
   red.template sum<6>(acc.g);
-  if (!local) {
+  if (!local && (Vb || lam != 0.0)) {                 // see k_normal_fused
     double Jl[9];
     left_jacobian(p, Jl);
     to_rodrigues_frame<NI>(Jl, acc.V, acc.W, acc.g);
@@ -652,21 +703,13 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
 #pragma unroll
     for (int e = 0; e < 6; ++e) gb[e * S + gv.slot] = acc.g[e];
   }
-#pragma unroll
-  for (int i = 0; i < NG; ++i) {
-    const double s = wave_sum(gacc.v[i]);
-    if (lane == 0) scratch[(size_t)i * scratch_stride + wave] = s;
-  }
+  wave_scatter_store<NG>(gacc.v, lane, scratch + wave, scratch_stride);
   if (local) return;
   double sacc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
   if (gv.gl == 0 && gv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc);
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const double s = wave_sum(sacc[i]);
-    if (lane == 0) scratch[(size_t)(NG + i) * scratch_stride + wave] = s;
-  }
+  wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + wave, scratch_stride);
 }
 
 // Evaluations A and B with G lanes per view (the pinhole LM driver's stages).
@@ -767,11 +810,7 @@ __global__ __launch_bounds__(TPB) void k_cross_schur_grp(camcal_tiles t, const d
     for (int e = 0; e < 6; ++e) g[e] = gb[e * S + gv.slot];
     lane_schur_regs<NI>(V, W, g, lam, sacc);
   }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    const double s = wave_sum(sacc[i]);
-    if (lane == 0) scratch[(size_t)i * scratch_stride + wave] = s;
-  }
+  wave_scatter_store<NS>(sacc, lane, scratch + wave, scratch_stride);
 }
 
 template <int MODEL>

@@ -99,10 +99,11 @@ template <int NI>
 CC_HD void lane_schur_regs(double V[21], double* W, double g[6], double lam, double* acc) {
   CC_UNROLL
   for (int i = 0; i < 6; ++i) V[tri(6, i, i)] *= 1.0 + lam;
-  chol6(V);
-  chol6_fwd(V, g);
+  double id[6];
+  chol6(V, id);
+  chol6_fwd(V, id, g);
   CC_UNROLL
-  for (int a = 0; a < NI; ++a) chol6_fwd(V, W + a * 6);
+  for (int a = 0; a < NI; ++a) chol6_fwd(V, id, W + a * 6);
   CC_UNROLL
   for (int a = 0; a < NI; ++a) {
     CC_UNROLL
@@ -274,15 +275,16 @@ CC_HD void lane_schur(const double* Vb, const double* Wb, const double* gb, long
     V[tri(6, i, i)] *= 1.0 + lam;
     z[i] = gb[i * S + slot];
   }
-  chol6(V);
-  chol6_fwd(V, z);
+  double id[6];
+  chol6(V, id);
+  chol6_fwd(V, id, z);
   double Y[NI * 6];
   CC_UNROLL
   for (int a = 0; a < NI; ++a) {
     double y[6];
     CC_UNROLL
     for (int c = 0; c < 6; ++c) y[c] = Wb[(a * 6 + c) * S + slot];
-    chol6_fwd(V, y);
+    chol6_fwd(V, id, y);
     CC_UNROLL
     for (int c = 0; c < 6; ++c) Y[a * 6 + c] = y[c];
   }

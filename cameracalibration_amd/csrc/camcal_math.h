@@ -532,6 +532,23 @@ CC_HD bool chol6(double V[21]) {
   }
   return ok;
 }
+// The same, also returning 1 / U_ii: the elimination substitutes NI + 1 vectors through
+// one factor, and six reciprocals replace 6 (NI + 1) divisions.
+CC_HD bool chol6(double V[21], double inv_diag[6]) {
+  const bool ok = chol6(V);
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) inv_diag[i] = 1.0 / V[tri(6, i, i)];
+  return ok;
+}
+CC_HD void chol6_fwd(const double U[21], const double inv_diag[6], double y[6]) {
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    double s = y[i];
+    CC_UNROLL
+    for (int k = 0; k < i; ++k) s -= U[tri(6, k, i)] * y[k];
+    y[i] = s * inv_diag[i];
+  }
+}
 // y <- U^-T y   (forward substitution with the upper factor)
 CC_HD void chol6_fwd(const double U[21], double y[6]) {
   CC_UNROLL
