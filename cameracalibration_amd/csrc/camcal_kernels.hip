@@ -116,13 +116,24 @@ __device__ __forceinline__ void wave_reduce_store(double* v, double* scratch, in
   wave_scatter_store<NV>(v, threadIdx.x & 63, scratch + wave_id, MAX_WAVES);
 }
 
+// this thread's share of a row of partials: elements tid, tid + TPB, ... in four independent
+// chains (several loads in flight; the order of the additions is fixed)
+__device__ __forceinline__ double strided_partial_sum(const double* __restrict__ row, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int w = threadIdx.x;
+  for (; w + 3 * TPB < n; w += 4 * TPB) {
+    s0 += row[w]; s1 += row[w + TPB]; s2 += row[w + 2 * TPB]; s3 += row[w + 3 * TPB];
+  }
+  for (; w < n; w += TPB) s0 += row[w];
+  return (s0 + s1) + (s2 + s3);
+}
+
 // second stage: out[i] = sum_w scratch[i][w], fixed order
 __global__ __launch_bounds__(TPB) void k_finalize(const double* __restrict__ scratch, int n_waves,
                                                   double* __restrict__ out) {
   __shared__ double sh[TPB];
   const int i = blockIdx.x;
-  double s = 0.0;
-  for (int w = threadIdx.x; w < n_waves; w += TPB) s += scratch[(size_t)i * MAX_WAVES + w];
+  const double s = strided_partial_sum(scratch + (size_t)i * MAX_WAVES, n_waves);
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int st = TPB / 2; st >= 1; st >>= 1) {
@@ -435,8 +446,7 @@ __global__ __launch_bounds__(TPB) void k_finalize_strided(const double* __restri
                                                           double* __restrict__ out) {
   __shared__ double sh[TPB];
   const int i = blockIdx.x;
-  double s = 0.0;
-  for (int w = threadIdx.x; w < n_part; w += TPB) s += scratch[(size_t)i * stride + w];
+  const double s = strided_partial_sum(scratch + (size_t)i * stride, n_part);
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int st = TPB / 2; st >= 1; st >>= 1) {
