@@ -53,6 +53,56 @@ __device__ __forceinline__ double wave_sum(double x) {
 // other to its partner (xor OFF), so the number of live values halves while the number of
 // lanes summed doubles.  Afterwards lane l holds, in v[i], the wavefront total of value
 // 64 i + bitreverse6(l); wave_scatter_store writes them out.
+// One exchange step on the pair (a, b) between lanes l and l ^ OFF: afterwards a holds, in
+// the lanes with bit OFF clear, what both lanes had in a, and b holds, in the lanes with the
+// bit set, what both had in b -- arranged so that a + b is the step's result in every lane.
+// OFF = 32 and 16 are single gfx950 instructions per dword (v_permlane32_swap: the upper
+// half of the first operand <-> the lower half of the second; v_permlane16_swap: odd rows
+// <-> even rows); the others go through the LDS crossbar (ds_bpermute).
+template <int OFF>
+__device__ __forceinline__ double pair_exchange_sum(double a, double b, bool up) {
+  if constexpr (OFF == 32 || OFF == 16) {
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (OFF == 32) {
+      const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+      const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+      return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+      const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+      return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+  } else {
+    const double send = up ? a : b, keep = up ? b : a;
+    return keep + __shfl_xor(send, OFF, 64);
+  }
+}
+
+// the reverse step: `own` is the total of a in the lanes with bit OFF clear and of b in the
+// others; returns both totals in every lane
+template <int OFF>
+__device__ __forceinline__ void pair_exchange_gather(double own, bool up, double& a, double& b) {
+  if constexpr (OFF == 32 || OFF == 16) {
+    const unsigned lo = (unsigned)__double2loint(own), hi = (unsigned)__double2hiint(own);
+    if constexpr (OFF == 32) {
+      const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      a = __hiloint2double((int)h[0], (int)l[0]);
+      b = __hiloint2double((int)h[1], (int)l[1]);
+    } else {
+      const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      a = __hiloint2double((int)h[0], (int)l[0]);
+      b = __hiloint2double((int)h[1], (int)l[1]);
+    }
+  } else {
+    const double got = __shfl_xor(own, OFF, 64);
+    a = up ? got : own;
+    b = up ? own : got;
+  }
+}
+
 template <int N, int OFF>
 struct WaveReduceScatter {
   static __device__ __forceinline__ void run(double* v, int lane) {
@@ -61,8 +111,7 @@ struct WaveReduceScatter {
 #pragma unroll
     for (int i = 0; i < H; ++i) {
       const double a = v[2 * i], b = (2 * i + 1 < N) ? v[2 * i + 1] : 0.0;
-      const double send = up ? a : b, keep = up ? b : a;
-      v[i] = keep + __shfl_xor(send, OFF, 64);
+      v[i] = pair_exchange_sum<OFF>(a, b, up);
     }
     WaveReduceScatter<H, OFF / 2>::run(v, lane);
   }
@@ -83,15 +132,15 @@ struct GroupAllReduce {
 #pragma unroll
     for (int i = 0; i < H; ++i) {
       const double a = v[2 * i], b = (2 * i + 1 < N) ? v[2 * i + 1] : 0.0;
-      const double send = up ? a : b, keep = up ? b : a;
-      v[i] = keep + __shfl_xor(send, OFF, 64);
+      v[i] = pair_exchange_sum<OFF>(a, b, up);
     }
     GroupAllReduce<H, OFF / 2>::run(v, lane);
 #pragma unroll
     for (int i = H - 1; i >= 0; --i) {
-      const double own = v[i], got = __shfl_xor(own, OFF, 64);
-      if (2 * i + 1 < N) v[2 * i + 1] = up ? own : got;
-      v[2 * i] = up ? got : own;
+      double a, b;
+      pair_exchange_gather<OFF>(v[i], up, a, b);
+      if (2 * i + 1 < N) v[2 * i + 1] = b;
+      v[2 * i] = a;
     }
   }
 };
