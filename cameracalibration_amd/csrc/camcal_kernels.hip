@@ -942,21 +942,133 @@ __global__ __launch_bounds__(TPB) void k_backsub(camcal_tiles t, const double* _
   wave_reduce_store<2>(acc, scratch, wave);
 }
 
-// Reduced solve on one lane (see camcal_lane.h: reduced_solve); the records and the
-// working matrix are staged in LDS by the whole wavefront first.
+// Reduced solve (U' - C) dK = b - d on the free intrinsics, the arithmetic of
+// camcal_lane.h: reduced_solve (Jacobi scaling, Gaussian elimination with partial
+// pivoting, intr_out = intr_in + scale dK, step norms) spread over one wavefront: lane i
+// holds row i of the scaled system in registers, the pivot row of every step is broadcast,
+// rows are never moved (a lane remembers the step at which its row was the pivot).
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
+                          __builtin_amdgcn_readlane(__double2loint(x), src));
+}
+
 __global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __restrict__ glob,
                                                       const double* __restrict__ schur, unsigned mask, double lam,
-                                                      double scale, const double* __restrict__ intr_in,
-                                                      double* __restrict__ intr_out, double* __restrict__ dK,
-                                                      double* __restrict__ stats) {
-  __shared__ double s_glob[56], s_schur[56], s_intr[16], s_ws[REDUCED_WS];
-  const int NU = NI * (NI + 1) / 2, lane = threadIdx.x;
-  if (lane < NU + NI + 1) s_glob[lane] = glob[lane];
-  if (lane < NU + NI) s_schur[lane] = schur[lane];
-  if (lane < NI) s_intr[lane] = intr_in[lane];
+                                                      double scale, const double* intr_in, double* intr_out,
+                                                      double* __restrict__ dK, double* __restrict__ stats) {
+  constexpr int MAXN = 9;
+  __shared__ double s_st[MAXN], s_in[MAXN], s_out[MAXN];
+  const int lane = threadIdx.x;
+  const int NU = NI * (NI + 1) / 2;
+  mask &= (1u << NI) - 1u;
+  const int nf = __popc(mask);
+  auto tr = [NI](int i, int j) { return i <= j ? i * NI - (i * (i - 1)) / 2 + (j - i) : j * NI - (j * (j - 1)) / 2 + (i - j); };
+  // parameter of this lane's row: the lane-th set bit of the mask
+  int a = 0;
+  {
+    int cnt = 0;
+    for (int b = 0; b < NI; ++b)
+      if ((mask >> b) & 1u) { if (cnt == lane) a = b; ++cnt; }
+  }
+  const bool active = lane < nf;
+  double sc = 1.0;
+  if (active) {
+    const double dd = glob[tr(a, a)] * (1.0 + lam) - schur[tr(a, a)];
+    sc = dd > 0.0 ? 1.0 / sqrt(dd) : 1.0;
+  }
+  double row[MAXN + 1];
+#pragma unroll
+  for (int j = 0; j < MAXN; ++j) {
+    const int b = __builtin_amdgcn_readlane(a, j);
+    const double scj = lane_bcast(sc, j);
+    double v = 0.0;
+    if (active && j < nf) {
+      double u = glob[tr(a, b)];
+      if (a == b) u *= 1.0 + lam;
+      v = (u - schur[tr(a, b)]) * sc * scj;
+    }
+    row[j] = v;
+  }
+  row[MAXN] = active ? (glob[NU + a] - schur[NU + a]) * sc : 0.0;
+  int pos = -1;                      // elimination step at which this row was the pivot
+  double okf = 1.0;
+#pragma unroll
+  for (int c = 0; c < MAXN; ++c) {
+    if (c < nf) {                    // uniform
+      const double val = (active && pos < 0) ? fabs(row[c]) : -1.0;
+      double best = 0.0;
+      int piv = -1;
+#pragma unroll
+      for (int r = 0; r < MAXN; ++r) {
+        const double vr = lane_bcast(val, r);
+        if (vr > best) { best = vr; piv = r; }
+      }
+      if (piv < 0) {                 // no usable pivot in this column
+        okf = 0.0;
+      } else {
+        double prow[MAXN + 1];
+#pragma unroll
+        for (int k = 0; k <= MAXN; ++k) prow[k] = (k >= c) ? lane_bcast(row[k], piv) : 0.0;
+        if (lane == piv) pos = c;
+        const double ip = 1.0 / prow[c];
+        if (active && pos < 0) {
+          const double f = row[c] * ip;
+          if (f != 0.0) {
+#pragma unroll
+            for (int k = 0; k < MAXN; ++k)
+              if (k >= c) row[k] -= f * prow[k];
+            row[MAXN] -= f * prow[MAXN];
+          }
+        }
+      }
+    }
+  }
+  // back substitution: x[c] comes from the row that was the pivot of step c
+  double x[MAXN];
+#pragma unroll
+  for (int c = 0; c < MAXN; ++c) x[c] = 0.0;
+#pragma unroll
+  for (int c = MAXN - 1; c >= 0; --c) {
+    if (c < nf) {                    // uniform
+      double sacc = row[MAXN];
+#pragma unroll
+      for (int k = 0; k < MAXN; ++k)
+        if (k > c) sacc -= row[k] * x[k];
+      const double mine = row[c] != 0.0 ? sacc / row[c] : 0.0;
+      const unsigned long long owner = __ballot(pos == c);
+      x[c] = owner ? lane_bcast(mine, __ffsll((long long)owner) - 1) : 0.0;
+    }
+  }
+  // this lane's own unknown (row i <-> column i of the scaled system), back to parameter units
+  double xi = 0.0;
+#pragma unroll
+  for (int c = 0; c < MAXN; ++c)
+    if (lane == c) xi = x[c];
+  if (lane < NI) {                   // non-free parameters first, the free ones overwrite theirs
+    const double in = intr_in[lane];
+    s_st[lane] = 0.0; s_in[lane] = in; s_out[lane] = in;
+  }
   __syncthreads();
-  if (lane != 0) return;
-  reduced_solve(NI, s_glob, s_schur, mask, lam, scale, s_intr, intr_out, dK, stats, s_ws);
+  if (active) {
+    const double d = xi * sc, in = intr_in[a], st = scale * d;
+    s_st[a] = st; s_out[a] = in + st;
+    dK[a] = d;
+  }
+  __syncthreads();
+  if (lane < NI) {
+    intr_out[lane] = s_out[lane];
+    if (!((mask >> lane) & 1u)) dK[lane] = 0.0;
+  }
+  if (lane == 0) {                   // the four step norms, summed in parameter order
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int p = 0; p < NI; ++p) {
+      const double st = s_st[p], in = s_in[p], out = s_out[p];
+      s0 += st * st;
+      s1 += in * in;
+      if (p < 4) { s2 += st * st; s3 += out * out; }
+    }
+    stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; stats[4] = okf;
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_pack_tiles(const float* __restrict__ obj, const float* __restrict__ img,
