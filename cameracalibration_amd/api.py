@@ -239,7 +239,7 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     E.pose_init(0, 0)
     E.pose_refine(0, 0, 20, 1e-10)
     comm = _comm or _solver.Comm()
-    log = [] if _info is not None else None
+    log = [] if (_info is not None and _info.get("log") is True) else None
     err, iters = _solver.lm_pinhole(E, mask, maxc, eps, comm=comm, log=log)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(err / n_total))
@@ -299,7 +299,7 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
     E.pose_init(0, 0)
     E.pose_refine(0, 0, 20, 1e-10)
     comm = _comm or _solver.Comm()
-    log = [] if _info is not None else None
+    log = [] if (_info is not None and _info.get("log") is True) else None
     cost, iters = _solver.gn_fisheye(E, mask, tuple(criteria),
                                      recompute_extrinsic=bool(flags & FISHEYE_CALIB_RECOMPUTE_EXTRINSIC),
                                      comm=comm, log=log)

@@ -1,0 +1,120 @@
+// Host-side sequencing of the two solver loops over the stage entry points of
+// include/camcal.h -- the loops that run inside OpenCV's C++ for the reference:
+//   cv::fisheye::calibrate's damped Gauss-Newton   (camcal_fisheye_gn)
+//   CvLevMarq::updateAlt inside cvCalibrateCamera2 (camcal_pinhole_lm)
+// One process, one device: a multi-rank solve needs an all-reduce between the
+// stages and is sequenced by the caller (cameracalibration_amd/solver.py).
+//
+// Included by camcal_kernels.hip and by the tests' CPU lane emulator; the
+// includer provides
+//   int camcal_read_back(double* dst_host, const double* src, int n, void* stream)
+//   int camcal_copy_doubles(double* dst, const double* src, int n, void* stream)
+// (device -> host with a stream synchronisation; device -> device on the stream).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/camcal.h"
+
+int camcal_read_back(double* dst_host, const double* src, int n, void* stream);
+int camcal_copy_doubles(double* dst, const double* src, int n, void* stream);
+
+#define CAMCAL_DRV_TRY(x)      \
+  do {                         \
+    const int rc_ = (x);       \
+    if (rc_ != 0) return rc_;  \
+  } while (0)
+
+extern "C" {
+
+int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
+                      int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec, double* dK,
+                      double* stats, int32_t* iters, double* scratch, void* stream, double* cost_out_host,
+                      int32_t* iterations_out_host) {
+  if (!tiles || !intr || !pose || !mask_host || !rec || !dK || !stats || !scratch || !cost_out_host ||
+      !iterations_out_host || crit_type < 1 || crit_type > 3)
+    return CAMCAL_E_BADARG;
+  const int ng = camcal_glob_len(CAMCAL_FISHEYE);
+  double change = 1.0;
+  int it = 0;
+  for (;;) {
+    if ((crit_type == 1 && it >= max_count) || (crit_type == 2 && change <= eps) ||
+        (crit_type == 3 && (change <= eps || it >= max_count)))
+      break;
+    const double alpha2 = 1.0 - std::pow(0.6, it + 1.0);
+    CAMCAL_DRV_TRY(camcal_normal_eq_fused(CAMCAL_FISHEYE, tiles, intr, pose, 0.0, nullptr, nullptr, nullptr, rec,
+                                          rec + ng, scratch, stream));
+    CAMCAL_DRV_TRY(camcal_solve_reduced(CAMCAL_FISHEYE, rec, rec + ng, mask_host, 0.0, -alpha2, intr, intr, dK,
+                                        stats, stream));
+    double st[5];
+    CAMCAL_DRV_TRY(camcal_read_back(st, stats, 5, stream));
+    change = std::sqrt(st[2]) / std::sqrt(st[3]);
+    if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
+    ++it;
+  }
+  CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
+                                    stream));
+  CAMCAL_DRV_TRY(camcal_read_back(cost_out_host, rec + ng - 1, 1, stream));
+  *iterations_out_host = it;
+  return 0;
+}
+
+int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double* const pose2[2],
+                      double* const V2[2], double* const g2[2], double* W, double* rec, double* glob_trial,
+                      double* dK, double* stats, double* norms, double* scratch, const uint8_t* mask_host,
+                      int max_iter, double eps, void* stream, double* err_out_host, int32_t* iterations_out_host,
+                      int32_t* current_out_host) {
+  if (!tiles || !intr2 || !pose2 || !V2 || !g2 || !W || !rec || !glob_trial || !dK || !stats || !norms || !scratch ||
+      !mask_host || !err_out_host || !iterations_out_host || !current_out_host)
+    return CAMCAL_E_BADARG;
+  for (int k = 0; k < 2; ++k)
+    if (!intr2[k] || !pose2[k] || !V2[k] || !g2[k]) return CAMCAL_E_BADARG;
+  const int M = CAMCAL_PINHOLE;
+  const int ng = camcal_glob_len(M);
+  double* glob = rec;                  // [U|b|cost] of the current point
+  double* schur = rec + ng;            // [C|d]
+  max_iter = max_iter < 1 ? 1 : (max_iter > 1000 ? 1000 : max_iter);
+  if (!(eps > 2.220446049250313e-16)) eps = 2.220446049250313e-16;
+  int cur = 0;                         // which physical buffer holds the current point
+  int lam_lg10 = -3, iters = 0;
+  CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[cur], pose2[cur], 1, glob, nullptr, V2[cur], g2[cur], scratch,
+                                    stream));
+  double err = 0.0;
+  CAMCAL_DRV_TRY(camcal_read_back(&err, glob + ng - 1, 1, stream));
+  for (;;) {
+    const int tri = 1 - cur;
+    const double prev_err = err;
+    double st[5] = {0, 0, 0, 0, 0}, nr[2] = {0, 0};
+    bool fresh = true;
+    for (;;) {
+      const double lam = std::pow(10.0, (double)lam_lg10);
+      // evaluation B at the current point for a fresh step, the stored blocks at another lambda otherwise
+      if (fresh) CAMCAL_DRV_TRY(camcal_cross_schur(M, tiles, intr2[cur], pose2[cur], V2[cur], g2[cur], lam, W, schur, scratch, stream));
+      else CAMCAL_DRV_TRY(camcal_schur(M, tiles, V2[cur], W, g2[cur], lam, schur, scratch, stream));
+      CAMCAL_DRV_TRY(camcal_solve_reduced(M, glob, schur, mask_host, lam, -1.0, intr2[cur], intr2[tri], dK, stats, stream));
+      CAMCAL_DRV_TRY(camcal_backsub(M, tiles, V2[cur], W, g2[cur], lam, dK, pose2[cur], pose2[tri], norms, scratch, stream));
+      CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[tri], pose2[tri], 1, glob_trial, nullptr, V2[tri], g2[tri],
+                                        scratch, stream));
+      CAMCAL_DRV_TRY(camcal_read_back(st, stats, 5, stream));
+      CAMCAL_DRV_TRY(camcal_read_back(nr, norms, 2, stream));
+      CAMCAL_DRV_TRY(camcal_read_back(&err, glob_trial + ng - 1, 1, stream));
+      if (!(err > prev_err)) break;
+      ++lam_lg10;
+      if (lam_lg10 > 16) break;
+      fresh = false;
+    }
+    lam_lg10 = lam_lg10 - 1 < -16 ? -16 : lam_lg10 - 1;
+    ++iters;
+    const double rel = std::sqrt(st[0] + nr[0]) / std::sqrt(st[1] + nr[1]);
+    // accept: the trial point becomes the current one
+    CAMCAL_DRV_TRY(camcal_copy_doubles(glob, glob_trial, ng, stream));
+    cur = tri;
+    if (iters >= max_iter || rel < eps) break;
+  }
+  *err_out_host = err;
+  *iterations_out_host = iters;
+  *current_out_host = cur;
+  return 0;
+}
+
+}  // extern "C"

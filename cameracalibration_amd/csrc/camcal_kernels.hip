@@ -1867,3 +1867,24 @@ int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------
+// Host-side solver loops (camcal_driver.h) and their two memory helpers.
+int camcal_read_back(double* dst_host, const double* src, int n, void* stream) {
+  // a small pinned landing buffer per host thread: the copy is a plain DMA, no staging
+  static thread_local double* pinned = nullptr;
+  constexpr int CAP = 64;
+  if (n <= 0 || n > CAP || !dst_host || !src) return CAMCAL_E_BADARG;
+  if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, CAP * sizeof(double), hipHostMallocDefault));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(pinned, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int i = 0; i < n; ++i) dst_host[i] = pinned[i];
+  return 0;
+}
+
+int camcal_copy_doubles(double* dst, const double* src, int n, void* stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+#include "camcal_driver.h"

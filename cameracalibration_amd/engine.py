@@ -251,6 +251,42 @@ class Engine:
                    self.pose[pose_out].data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(),
                    self._stream())
 
+    # -- whole solves sequenced by the library (single rank) ---------------------------
+    @staticmethod
+    def _mask_bytes(mask):
+        return bytes(bytearray(int(bool(x)) for x in mask))
+
+    def solve_fisheye(self, mask, criteria, recompute_extrinsic=True):
+        """cv::fisheye::calibrate's loop from ``intr[0]`` / ``pose[0]`` (camcal_fisheye_gn).
+        Returns (sum of squared residuals, iterations)."""
+        ctype, maxc, eps = criteria
+        cost, its = C.c_double(0.0), C.c_int32(0)
+        self._call("camcal_fisheye_gn", self._tp(), self.intr[0].data_ptr(), self.pose[0].data_ptr(),
+                   self._mask_bytes(mask), int(ctype), int(maxc), float(eps), 1 if recompute_extrinsic else 0,
+                   self.rec.data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(), self.iters.data_ptr(),
+                   self.scratch.data_ptr(), self._stream(), C.byref(cost), C.byref(its))
+        return float(cost.value), int(its.value)
+
+    def solve_pinhole(self, mask, max_iter, eps):
+        """CvLevMarq loop from ``intr[0]`` / ``pose[0]`` (camcal_pinhole_lm); on return
+        buffer 0 holds the result.  Returns (errNorm2, iterations)."""
+        two = C.c_void_p * 2
+        err, its, cur = C.c_double(0.0), C.c_int32(0), C.c_int32(0)
+        self._call("camcal_pinhole_lm", self._tp(),
+                   two(self.intr[0].data_ptr(), self.intr[1].data_ptr()),
+                   two(self.pose[0].data_ptr(), self.pose[1].data_ptr()),
+                   two(self.Vs[0].data_ptr(), self.Vs[1].data_ptr()),
+                   two(self.gs[0].data_ptr(), self.gs[1].data_ptr()),
+                   self.W.data_ptr(), self.rec.data_ptr(), self.glob[1].data_ptr(), self.dK.data_ptr(),
+                   self.stats.data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(), self._mask_bytes(mask),
+                   int(max_iter), float(eps), self._stream(), C.byref(err), C.byref(its), C.byref(cur))
+        if cur.value == 1:                   # the result sits in the second buffers: make them buffer 0
+            self.intr.reverse()
+            self.pose.reverse()
+            self.Vs.reverse()
+            self.gs.reverse()
+        return float(err.value), int(its.value)
+
     def normal_eq(self, intr_idx, pose_idx, lam, store_blocks=True, fused=False):
         """One full normal-equation evaluation (the benchmarked unit) into
         ``self.rec`` = [U|b|cost|C|d].  ``fused``: single pass over the points

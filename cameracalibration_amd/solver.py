@@ -59,6 +59,8 @@ def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
     comm = comm or Comm(enabled=False)
     max_iter = int(min(max(max_iter, 1), 1000))
     eps = max(float(eps), DBL_EPSILON)
+    if not comm.enabled and log is None:
+        return E.solve_pinhole(mask, max_iter, eps)       # same loop, sequenced by the library
     lam_lg10 = -3
     cur, tri = 0, 1
     cost_idx = E.glob_len - 1
@@ -110,6 +112,8 @@ def gn_fisheye(E, mask, criteria, recompute_extrinsic=True, comm=None, log=None)
     (CalibrateExtrinsics).  Returns (cost, iterations)."""
     comm = comm or Comm(enabled=False)
     ctype, maxc, eps = criteria
+    if not comm.enabled and log is None:
+        return E.solve_fisheye(mask, (ctype, maxc, eps), recompute_extrinsic)   # same loop, in the library
     change, it = 1.0, 0
     cost_idx = E.glob_len - 1
     while True:

@@ -174,12 +174,43 @@ int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr,
                      double* glob, double* schur, double* scratch, void* stream);
 
 /* Same results from ONE pass over the points with every accumulator of a view
- * in one lane (kept for comparison: it runs at one wavefront per SIMD and is
- * slower on gfx950).  Needs schur == glob + camcal_glob_len;
+ * in one lane (what the fisheye driver and the benchmark use: the points are read
+ * once).  Needs schur == glob + camcal_glob_len;
  * V, W, g all NULL or all set. */
 int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* intr,
                            const double* pose, double lam, double* V, double* W, double* g,
                            double* glob, double* schur, double* scratch, void* stream);
+
+/* ---- Host-side sequencing of whole solves on ONE device (one process): the loops that
+ * run inside OpenCV's C++ behind the two reference calls.  They only call the stage entry
+ * points above and read a few scalars back per iteration (stream-synchronising); a
+ * multi-rank solve needs an all-reduce between the stages and is sequenced by the caller.
+ * _host pointers are host memory, everything else is device memory. */
+
+/* cv::fisheye::calibrate's loop (camera_calib.py:74-77): until the criteria stop it
+ * (crit_type 1 = COUNT, 2 = EPS, 3 = both; `change` = relative step of fx fy cx cy):
+ * single-pass evaluation, reduced solve with the step damped by 1 - 0.6^(it+1), and --
+ * with recompute_extrinsic (CALIB_RECOMPUTE_EXTRINSIC) -- re-estimation of every pose.
+ * intr, pose: starting point in, result out.  rec: camcal_glob_len + camcal_schur_len
+ * doubles, dK 16, stats 8, iters [n_slots] (may be NULL), scratch camcal_scratch_len.
+ * cost_out_host = sum of squared residuals at the result. */
+int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
+                      int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec,
+                      double* dK, double* stats, int32_t* iters, double* scratch, void* stream,
+                      double* cost_out_host, int32_t* iterations_out_host);
+
+/* CvLevMarq::updateAlt as cvCalibrateCamera2Internal drives it (camera_calib.py:153-156) on
+ * the eliminated system: lambda starts at 1e-3, x10 on a rejected step (only the stored-
+ * block Schur kernel is repeated), /10 on an accepted one; stops after max_iter accepted
+ * steps or when the relative parameter change < eps.  intr2 / pose2 / V2 / g2: the two
+ * buffers of each double-buffered quantity (HOST arrays of two device pointers; [0] holds
+ * the starting point), W NI*6*n_slots, rec as above, glob_trial camcal_glob_len, norms 2.
+ * current_out_host = index (0 / 1) of the buffers that hold the result. */
+int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double* const pose2[2],
+                      double* const V2[2], double* const g2[2], double* W, double* rec,
+                      double* glob_trial, double* dK, double* stats, double* norms, double* scratch,
+                      const uint8_t* mask_host, int max_iter, double eps, void* stream,
+                      double* err_out_host, int32_t* iterations_out_host, int32_t* current_out_host);
 
 /* Timing helper for benchmarks: average duration in milliseconds of `reps`
  * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,

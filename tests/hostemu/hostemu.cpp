@@ -533,3 +533,16 @@ int camcal_remap_u8(const unsigned char* src, int sw, int sh, int64_t sstride, i
 }
 int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 0.0; return 0; }
 }  // extern "C"
+
+// Host-side solver loops: the same sequencing code as the HIP library, over this emulator's stages.
+#include <cstring>
+int camcal_read_back(double* dst_host, const double* src, int n, void*) {
+  if (n <= 0 || !dst_host || !src) return CAMCAL_E_BADARG;
+  std::memcpy(dst_host, src, (size_t)n * sizeof(double));
+  return 0;
+}
+int camcal_copy_doubles(double* dst, const double* src, int n, void*) {
+  std::memmove(dst, src, (size_t)n * sizeof(double));
+  return 0;
+}
+#include "../../cameracalibration_amd/csrc/camcal_driver.h"

@@ -176,6 +176,23 @@ def test_config3_ragged_subsample_vs_oracle(dev, mapping):
     assert abs(r[0] - o[0]) < 1e-9 and np.allclose(r[1], o[1], rtol=1e-9) and np.allclose(r[2], o[2], rtol=1e-6, atol=1e-11)
 
 
+def test_library_sequenced_loops_equal_the_python_loops_on_gpu(dev):
+    """camcal_fisheye_gn / camcal_pinhole_lm (single rank, default) against the same loops
+    sequenced by solver.py (chosen by asking for the iteration log): identical stage calls."""
+    for cfg, nv in (("C1", 20), ("C2", 200)):
+        P = synth.config(cfg, n_views=nv)
+        objs, imgs = P.as_lists()
+        res = []
+        for info in ({}, {"log": True}):
+            fn, fl = (cc.calibrateCamera, 1) if P.model == "pinhole" else (cc.fisheye.calibrate, FE)
+            r = fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT, _info=info)
+            res.append((r, info))
+        (a, ia), (b, ib) = res
+        assert ia["log"] is None and len(ib["log"]) == ib["iters"] == ia["iters"]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(np.hstack(a[3]), np.hstack(b[3]))
+
+
 def test_noise_free_ground_truth_on_gpu(dev):
     P = synth.config("C2", n_views=300, noise=0.0)
     objs, imgs = P.as_lists()

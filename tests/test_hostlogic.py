@@ -135,6 +135,28 @@ def test_fix_flags(emu):
     assert np.allclose(Ko, o[1], rtol=1e-9) and np.allclose(Do, o[2], atol=1e-11)
 
 
+def test_library_sequenced_loops_equal_the_python_loops(emu):
+    """Single rank: the solver loops run inside the library (camcal_fisheye_gn / camcal_pinhole_lm);
+    asking for the iteration log (or more than one rank) keeps them in solver.py.  Same stage
+    calls in the same order, so the results are identical."""
+    for cfg, nv in (("C1", 20), ("C2", 40), ("C3", 90)):
+        P = synth.config(cfg, n_views=nv)
+        objs, imgs = P.as_lists()
+        res = []
+        for info in ({}, {"log": True}):
+            if P.model == "pinhole":
+                r = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1,
+                                       criteria=CRIT, _info=info, **_emu_kw(emu))
+            else:
+                r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE,
+                                         criteria=CRIT, _info=info, **_emu_kw(emu))
+            res.append((r, info))
+        (a, ia), (b, ib) = res
+        assert ia["log"] is None and len(ib["log"]) == ib["iters"] == ia["iters"]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(np.hstack(a[3]), np.hstack(b[3])) and np.array_equal(np.hstack(a[4]), np.hstack(b[4]))
+
+
 def test_view_lists_in_any_array_form():
     """Lists of ndarrays (the reference: float32 (n,1,3)/(n,1,2), camera_calib.py:70-75) take one
     concatenation; anything else (nested lists, float64, (n,3)) is converted per view -- same result."""
