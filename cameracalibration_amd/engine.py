@@ -64,7 +64,7 @@ class Engine:
             raise _lib.CamcalError("unknown camera model")
         self.glob_len = self.lib.camcal_glob_len(self.model)
         self.schur_len = self.lib.camcal_schur_len(self.model)
-        view_ptr = np.asarray(torch.as_tensor(view_ptr).cpu().numpy(), dtype=np.int64)
+        view_ptr = np.ascontiguousarray(torch.as_tensor(view_ptr).cpu().numpy(), dtype=np.int64)
         n = np.diff(view_ptr)
         self.n_views = int(n.shape[0])
         self.n_obs = int(view_ptr[-1])
@@ -73,12 +73,18 @@ class Engine:
         self.layout = lay
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
-        self.t_slot_view = torch.from_numpy(lay["slot_view"]).to(dev)
-        self.t_lane_n = torch.from_numpy(lay["lane_n"]).to(dev)
-        self.t_tile_nmax = torch.from_numpy(lay["tile_nmax"]).to(dev)
-        self.t_tile_off = torch.from_numpy(lay["tile_off"]).to(dev)
-        self.t_pts = torch.zeros(max(lay["total_floats"], 1), dtype=torch.float32, device=dev)
-        S = lay["n_slots"]
+        # layout tables + CSR offsets: one upload, carved up (int64 tables first: alignment)
+        T, S = lay["n_tiles"], lay["n_slots"]
+        tab = np.concatenate([lay["tile_off"].view(np.int32), view_ptr.view(np.int32), lay["slot_view"],
+                              lay["lane_n"], lay["tile_nmax"]])
+        t_tab = torch.from_numpy(tab).to(dev)
+        o = 0
+        self.t_tile_off = t_tab[o:o + 2 * T].view(torch.int64); o += 2 * T
+        t_vp = t_tab[o:o + 2 * (self.n_views + 1)].view(torch.int64); o += 2 * (self.n_views + 1)
+        self.t_slot_view = t_tab[o:o + S]; o += S
+        self.t_lane_n = t_tab[o:o + S]; o += S
+        self.t_tile_nmax = t_tab[o:o + T]
+        self.t_pts = torch.empty(max(lay["total_floats"], 1), dtype=torch.float32, device=dev)   # pack writes all of it
         self.S = S
         self.tiles = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off.data_ptr(),
                                 self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
@@ -94,7 +100,6 @@ class Engine:
         t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
         if t_obj.shape[0] != self.n_obs or t_img.shape[0] != self.n_obs:
             raise ValueError("view_ptr does not match the point arrays")
-        t_vp = torch.from_numpy(view_ptr).to(dev)
         self._call("camcal_pack_tiles", t_obj.data_ptr(), t_img.data_ptr(), t_vp.data_ptr(),
                    self.t_slot_view.data_ptr(), C.byref(self.tiles), self.t_pts.data_ptr(), self._stream())
         self._sync()
@@ -129,8 +134,8 @@ class Engine:
         self.view_cost = part["view_cost"]
         # partial sums: every entry a launch reads was written by that launch
         self.scratch = torch.empty(int(self.lib.camcal_scratch_len(self.model, lay["n_tiles"])), **f64)
-        self.status = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.iters = torch.zeros(S, dtype=torch.int32, device=dev)
+        ints = torch.zeros(2 * S, dtype=torch.int32, device=dev)
+        self.status, self.iters = ints[:S], ints[S:]
 
     # -- plumbing ------------------------------------------------------------
     def _stream(self):
