@@ -206,9 +206,10 @@ CC_HD bool pose_gn_update(double V[21], double g[6], double pose[6], double& cha
   double Jl[9];
   left_jacobian(pose, Jl);
   vg_to_rodrigues_frame(Jl, V, g);
-  const bool ok = chol6(V);
-  chol6_fwd(V, g);
-  chol6_bwd(V, g);
+  double id[6];
+  const bool ok = chol6(V, id);
+  chol6_fwd(V, id, g);
+  chol6_bwd(V, id, g);
   if (!ok) return false;
   double d2 = 0.0, x2 = 0.0;
   CC_UNROLL
@@ -325,9 +326,10 @@ CC_HD void lane_backsub(const double* Vb, const double* Wb, const double* gb, lo
     CC_UNROLL
     for (int c = 0; c < 6; ++c) rhs[c] -= Wb[(a * 6 + c) * S + slot] * dk;
   }
-  chol6(V);
-  chol6_fwd(V, rhs);
-  chol6_bwd(V, rhs);
+  double id[6];
+  chol6(V, id);
+  chol6_fwd(V, id, rhs);
+  chol6_bwd(V, id, rhs);
   dd = 0.0; pp = 0.0;
   CC_UNROLL
   for (int i = 0; i < 6; ++i) {

@@ -549,6 +549,15 @@ CC_HD void chol6_fwd(const double U[21], const double inv_diag[6], double y[6]) 
     y[i] = s * inv_diag[i];
   }
 }
+CC_HD void chol6_bwd(const double U[21], const double inv_diag[6], double y[6]) {
+  CC_UNROLL
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    CC_UNROLL
+    for (int k = i + 1; k < 6; ++k) s -= U[tri(6, i, k)] * y[k];
+    y[i] = s * inv_diag[i];
+  }
+}
 // y <- U^-T y   (forward substitution with the upper factor)
 CC_HD void chol6_fwd(const double U[21], double y[6]) {
   CC_UNROLL
