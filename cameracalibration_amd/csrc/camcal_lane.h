@@ -346,11 +346,12 @@ template <int MODEL> CC_HD void undistort_px(double u, double v, const double* i
 // cvUndistortPointsInternal: 5 fixed-point sweeps
 template <> CC_HD void undistort_px<PINHOLE>(double u, double v, const double* intr, double& mx, double& my) {
   const double k1 = intr[4], k2 = intr[5], p1 = intr[6], p2 = intr[7], k3 = intr[8];
-  const double x0 = (u - intr[2]) / intr[0], y0 = (v - intr[3]) / intr[1];
+  const double ifx = 1.0 / intr[0], ify = 1.0 / intr[1];      // invariant over the points of a launch
+  const double x0 = (u - intr[2]) * ifx, y0 = (v - intr[3]) * ify;
   double x = x0, y = y0;
   for (int it = 0; it < 5; ++it) {
     const double r2 = x * x + y * y;
-    const double icd = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
+    const double icd = fast_rcp(1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
     if (icd < 0) { x = x0; y = y0; break; }
     const double dX = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
     const double dY = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
@@ -363,8 +364,11 @@ template <> CC_HD void undistort_px<PINHOLE>(double u, double v, const double* i
 // cv::fisheye::undistortPoints: Newton on theta (<= 10 steps, |fix| < 1e-8)
 template <> CC_HD void undistort_px<FISHEYE>(double u, double v, const double* intr, double& mx, double& my) {
   const double k1 = intr[4], k2 = intr[5], k3 = intr[6], k4 = intr[7];
-  const double px = (u - intr[2]) / intr[0], py = (v - intr[3]) / intr[1];
-  double thd = sqrt(px * px + py * py);
+  const double ifx = 1.0 / intr[0], ify = 1.0 / intr[1];      // invariant over the points of a launch
+  const double px = (u - intr[2]) * ifx, py = (v - intr[3]) * ify;
+  const double p2 = px * px + py * py;
+  double thd = 0.0;
+  if (p2 > 0.0) fast_rsqrt(p2, thd);
   const double hp = 1.5707963267948966;
   thd = thd > hp ? hp : thd;
   double scale = 1.0;
@@ -372,12 +376,12 @@ template <> CC_HD void undistort_px<FISHEYE>(double u, double v, const double* i
     double th = thd;
     for (int j = 0; j < 10; ++j) {
       const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-      const double fix = (th * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8) - thd) /
-                         (1 + 3 * k1 * t2 + 5 * k2 * t4 + 7 * k3 * t6 + 9 * k4 * t8);
+      const double fix = (th * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8) - thd) *
+                         fast_rcp(1 + 3 * k1 * t2 + 5 * k2 * t4 + 7 * k3 * t6 + 9 * k4 * t8);
       th -= fix;
       if (fabs(fix) < 1e-8) break;
     }
-    scale = tan(th) / thd;
+    scale = tan_acute(th) * fast_rcp(thd);
   }
   mx = px * scale; my = py * scale;
 }
@@ -448,6 +452,46 @@ CC_HD void rot_to_rvec(const double R[9], double r[3]) {
 // undistort -> homography (normalised DLT, then Gauss-Newton on the transfer
 // error, <= 10 steps) -> (u1, u2 - (u1.u2)u1, u1 x u2) -> Rodrigues vector,
 // t = h3 / sc - R [mx my 0]^T.  Returns 0 on success.
+// Normal equations of the homography fit.  The two rows of a corner are [a 0 c0 | e0] and
+// [0 a c1 | e1] (a: 3 entries, c0, c1: 2), so of the 36 + 8 sums only 29 are distinct and
+// none of the structural zeros is multiplied: S = [a a^T (6) | a c0^T (6) | a c1^T (6) |
+// c0 c0^T + c1 c1^T (3) | a e0 (3) | a e1 (3) | c0 e0 + c1 e1 (2)].
+CC_HD void homography_accumulate(const double a[3], const double c0[2], const double c1[2], double e0, double e1,
+                                 double S[29]) {
+  S[0] = fma(a[0], a[0], S[0]); S[1] = fma(a[0], a[1], S[1]); S[2] = fma(a[0], a[2], S[2]);
+  S[3] = fma(a[1], a[1], S[3]); S[4] = fma(a[1], a[2], S[4]); S[5] = fma(a[2], a[2], S[5]);
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    S[6 + i * 2] = fma(a[i], c0[0], S[6 + i * 2]);
+    S[7 + i * 2] = fma(a[i], c0[1], S[7 + i * 2]);
+    S[12 + i * 2] = fma(a[i], c1[0], S[12 + i * 2]);
+    S[13 + i * 2] = fma(a[i], c1[1], S[13 + i * 2]);
+    S[21 + i] = fma(a[i], e0, S[21 + i]);
+    S[24 + i] = fma(a[i], e1, S[24 + i]);
+  }
+  S[18] = fma(c0[0], c0[0], fma(c1[0], c1[0], S[18]));
+  S[19] = fma(c0[0], c0[1], fma(c1[0], c1[1], S[19]));
+  S[20] = fma(c0[1], c0[1], fma(c1[1], c1[1], S[20]));
+  S[27] = fma(c0[0], e0, fma(c1[0], e1, S[27]));
+  S[28] = fma(c0[1], e0, fma(c1[1], e1, S[28]));
+}
+// the 29 sums -> packed upper triangle of the 8 x 8 matrix and the right-hand side
+CC_HD void homography_expand(const double S[29], double A[36], double b[8]) {
+  const double aa[3][3] = {{S[0], S[1], S[2]}, {S[1], S[3], S[4]}, {S[2], S[4], S[5]}};
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i) {
+    CC_UNROLL
+    for (int j = i; j < 3; ++j) { A[tri(8, i, j)] = aa[i][j]; A[tri(8, 3 + i, 3 + j)] = aa[i][j]; }
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j) A[tri(8, i, 3 + j)] = 0.0;
+    A[tri(8, i, 6)] = S[6 + i * 2]; A[tri(8, i, 7)] = S[7 + i * 2];
+    A[tri(8, 3 + i, 6)] = S[12 + i * 2]; A[tri(8, 3 + i, 7)] = S[13 + i * 2];
+    b[i] = S[21 + i]; b[3 + i] = S[24 + i];
+  }
+  A[tri(8, 6, 6)] = S[18]; A[tri(8, 6, 7)] = S[19]; A[tri(8, 7, 7)] = S[20];
+  b[6] = S[27]; b[7] = S[28];
+}
+
 // The corners k0, k0 + step, ... of the view are walked by this lane; red.sum<M>(a) makes
 // the M sums in a[] complete (nothing to do when one lane walks the whole view, a
 // butterfly over the lanes that share the view otherwise -- every lane then holds the
@@ -473,28 +517,20 @@ CC_HD int pose_init_walk(const float* base, int n, int k0, int step, const doubl
   double dX = sqrt(fmax(sxx * inv_n - mX * mX, 0.0)), dY = sqrt(fmax(syy * inv_n - mY * mY, 0.0));
   const double iX = dX > 1e-300 ? 1.0 / dX : 1.0, iY = dY > 1e-300 ? 1.0 / dY : 1.0;
   // pass 2: inhomogeneous DLT (h33 = 1) in normalised board coordinates
-  double A[36], b[8];
+  double A[36], b[8], S[29];
   CC_UNROLL
-  for (int i = 0; i < 36; ++i) A[i] = 0.0;
-  CC_UNROLL
-  for (int i = 0; i < 8; ++i) b[i] = 0.0;
+  for (int i = 0; i < 29; ++i) S[i] = 0.0;
   for (int k = k0; k < n; k += step) {
     const Obs o = load_obs<true>(base, k);
     double x, y;
     undistort_px<MODEL>(o.u, o.v, intr, x, y);
     const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
     // rows: [X Y 1 0 0 0 -xX -xY | x], [0 0 0 X Y 1 -yX -yY | y]
-    const double r0[8] = {X, Y, 1.0, 0.0, 0.0, 0.0, -x * X, -x * Y};
-    const double r1[8] = {0.0, 0.0, 0.0, X, Y, 1.0, -y * X, -y * Y};
-    CC_UNROLL
-    for (int i = 0; i < 8; ++i) {
-      CC_UNROLL
-      for (int j = i; j < 8; ++j) A[tri(8, i, j)] += r0[i] * r0[j] + r1[i] * r1[j];
-      b[i] += r0[i] * x + r1[i] * y;
-    }
+    const double a[3] = {X, Y, 1.0}, c0[2] = {-x * X, -x * Y}, c1[2] = {-y * X, -y * Y};
+    homography_accumulate(a, c0, c1, x, y, S);
   }
-  red.template sum<36>(A);
-  red.template sum<8>(b);
+  red.template sum<29>(S);
+  homography_expand(S, A, b);
   if (!chol_solve<8>(A, b)) return 2;
   double h[8];
   CC_UNROLL
@@ -502,29 +538,20 @@ CC_HD int pose_init_walk(const float* base, int n, int k0, int step, const doubl
   // Gauss-Newton on the transfer error  sum |H X - m|^2
   for (int it = 0; it < 10; ++it) {
     CC_UNROLL
-    for (int i = 0; i < 36; ++i) A[i] = 0.0;
-    CC_UNROLL
-    for (int i = 0; i < 8; ++i) b[i] = 0.0;
+    for (int i = 0; i < 29; ++i) S[i] = 0.0;
     for (int k = k0; k < n; k += step) {
       const Obs o = load_obs<true>(base, k);
       double x, y;
       undistort_px<MODEL>(o.u, o.v, intr, x, y);
       const double X = (o.X - mX) * iX, Y = (o.Y - mY) * iY;
-      const double iw = 1.0 / (h[6] * X + h[7] * Y + 1.0);
+      const double iw = fast_rcp(h[6] * X + h[7] * Y + 1.0);
       const double px = (h[0] * X + h[1] * Y + h[2]) * iw, py = (h[3] * X + h[4] * Y + h[5]) * iw;
-      const double ex = px - x, ey = py - y;
       const double Xw = X * iw, Yw = Y * iw;
-      const double r0[8] = {Xw, Yw, iw, 0.0, 0.0, 0.0, -px * Xw, -px * Yw};
-      const double r1[8] = {0.0, 0.0, 0.0, Xw, Yw, iw, -py * Xw, -py * Yw};
-      CC_UNROLL
-      for (int i = 0; i < 8; ++i) {
-        CC_UNROLL
-        for (int j = i; j < 8; ++j) A[tri(8, i, j)] += r0[i] * r0[j] + r1[i] * r1[j];
-        b[i] += r0[i] * ex + r1[i] * ey;
-      }
+      const double a[3] = {Xw, Yw, iw}, c0[2] = {-px * Xw, -px * Yw}, c1[2] = {-py * Xw, -py * Yw};
+      homography_accumulate(a, c0, c1, px - x, py - y, S);
     }
-    red.template sum<36>(A);
-    red.template sum<8>(b);
+    red.template sum<29>(S);
+    homography_expand(S, A, b);
     if (!chol_solve<8>(A, b)) break;
     double dmax = 0.0, hmax = 0.0;
     CC_UNROLL
@@ -533,7 +560,10 @@ CC_HD int pose_init_walk(const float* base, int n, int k0, int step, const doubl
       dmax = fmax(dmax, fabs(b[i]));
       hmax = fmax(hmax, fabs(h[i]));
     }
-    if (dmax <= 1e-13 * hmax) break;
+    // Gauss-Newton converges quadratically here: a step below 1e-8 leaves an error near
+    // 1e-16, so the pass that would only confirm it is not run (cv2's LM refinement of
+    // the homography stops at FLT_EPSILON)
+    if (dmax <= 1e-8 * hmax) break;
   }
   // columns of the homography in centred board millimetres
   double h1[3] = {h[0] * iX, h[3] * iX, h[6] * iX};

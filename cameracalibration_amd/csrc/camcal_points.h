@@ -76,8 +76,11 @@ CC_HD void undistort_point<PINHOLE>(double u, double v, const double* intr, cons
 template <>
 CC_HD void undistort_point<FISHEYE>(double u, double v, const double* intr, const double* M, double& ox, double& oy) {
   const double k1 = intr[4], k2 = intr[5], k3 = intr[6], k4 = intr[7];
-  const double px = (u - intr[2]) / intr[0], py = (v - intr[3]) / intr[1];
-  double thd = sqrt(px * px + py * py);
+  const double ifx = 1.0 / intr[0], ify = 1.0 / intr[1];
+  const double px = (u - intr[2]) * ifx, py = (v - intr[3]) * ify;
+  const double p2 = px * px + py * py;
+  double thd = 0.0;
+  if (p2 > 0.0) fast_rsqrt(p2, thd);
   const double hp = 1.5707963267948966;
   thd = thd > hp ? hp : thd;
   bool converged = false;
@@ -85,12 +88,12 @@ CC_HD void undistort_point<FISHEYE>(double u, double v, const double* intr, cons
   if (thd > 1e-8) {
     for (int j = 0; j < 10; ++j) {
       const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-      const double fix = (th * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8) - thd) /
-                         (1 + 3 * k1 * t2 + 5 * k2 * t4 + 7 * k3 * t6 + 9 * k4 * t8);
+      const double fix = (th * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8) - thd) *
+                         fast_rcp(1 + 3 * k1 * t2 + 5 * k2 * t4 + 7 * k3 * t6 + 9 * k4 * t8);
       th -= fix;
       if (fabs(fix) < 1e-8) { converged = true; break; }
     }
-    scale = tan(th) / thd;
+    scale = tan_acute(th) * fast_rcp(thd);
   } else {
     converged = true;
   }
