@@ -3,9 +3,11 @@
 // Mapping: one lane == one view, one wavefront == one tile of 64 views, points
 // packed so that corner k of the 64 views of a tile is one coalesced 256-byte
 // row per component (see include/camcal.h).  All accumulators of a view live
-// in that lane's registers; the only cross-lane traffic is the 64-lane
-// butterfly at the end of the reducing kernels, followed by a fixed-order
-// second stage (deterministic sums).  FP64 VALU bound; no MFMA, no LDS tiling.
+// in that lane's registers; the only cross-lane traffic is the reduction of
+// the tile's partial sums at the end of the reducing kernels (halving
+// exchanges, WaveReduceScatter), followed by a fixed-order second stage
+// (deterministic sums).  Small view sets give a view 16 or 64 lanes instead
+// (group_lanes).  FP64 VALU bound; no MFMA, no LDS tiling.
 //
 // Replaces the arithmetic the reference delegates to cv2.calibrateCamera /
 // cv2.fisheye.calibrate (server/aruco/camera_calib.py:74-77,153-156).
