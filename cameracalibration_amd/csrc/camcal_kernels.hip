@@ -1876,7 +1876,7 @@ int camcal_read_back(double* dst_host, const double* src, int n, void* stream) {
   static thread_local double* pinned = nullptr;
   constexpr int CAP = 64;
   if (n <= 0 || n > CAP || !dst_host || !src) return CAMCAL_E_BADARG;
-  if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, CAP * sizeof(double), hipHostMallocDefault));
+  if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, CAP * sizeof(double), hipHostMallocPortable));
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(pinned, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
