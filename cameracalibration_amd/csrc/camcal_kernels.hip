@@ -432,6 +432,9 @@ __global__ __launch_bounds__(TPB) void k_rig_assemble(int64_t S, int n_tiles, co
   wave_reduce_store<NACC>(acc, scratch, wave);
 }
 
+// blockIdx.y selects a chunk of RIG_SCHUR_CHUNK columns of Wp: the factorisation of the
+// pose block is cheap next to the latency of walking all n_cams * G columns in one thread
+constexpr int RIG_SCHUR_CHUNK = 8;
 template <int G>
 __global__ __launch_bounds__(TPB) void k_rig_pose_schur(int n_cams, int64_t P, const double* __restrict__ Vp_all,
                                                         const double* __restrict__ gp_all,
@@ -442,18 +445,20 @@ __global__ __launch_bounds__(TPB) void k_rig_pose_schur(int n_cams, int64_t P, c
   double U[21], g[6];
   const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, g);
   const int64_t ld = (int64_t)n_cams * G;
-  if (ok) chol6_fwd(U, g);
+  if (blockIdx.y == 0) {
+    if (ok) chol6_fwd(U, g);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) z[p * 6 + k] = ok ? g[k] : 0.0;
-  for (int c = 0; c < n_cams; ++c) {
-    for (int a = 0; a < G; ++a) {
-      double y[6];
+    for (int k = 0; k < 6; ++k) z[p * 6 + k] = ok ? g[k] : 0.0;
+  }
+  const int v0 = blockIdx.y * RIG_SCHUR_CHUNK;
+  const int v1 = v0 + RIG_SCHUR_CHUNK < (int)ld ? v0 + RIG_SCHUR_CHUNK : (int)ld;
+  for (int v = v0; v < v1; ++v) {                 // v = c * G + a
+    double y[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) y[k] = Wp_all[(((int64_t)c * G + a) * 6 + k) * P + p];
-      if (ok) chol6_fwd(U, y);
+    for (int k = 0; k < 6; ++k) y[k] = Wp_all[((int64_t)v * 6 + k) * P + p];
+    if (ok) chol6_fwd(U, y);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Y[(p * 6 + k) * ld + c * G + a] = ok ? y[k] : 0.0;
-    }
+    for (int k = 0; k < 6; ++k) Y[(p * 6 + k) * ld + v] = ok ? y[k] : 0.0;
   }
 }
 
@@ -1251,7 +1256,17 @@ __global__ __launch_bounds__(TPB) void k_remap_u8(const unsigned char* __restric
   remap_pixel_u8(src, sw, sh, sstride, cn, ix, iy, fx, fy, cval, dst + (long long)i * dstride + (long long)j * cn);
 }
 
-// Reduced solve of the rig on one wavefront (camcal_rig.h: rig_solve_*).
+// Reduced solve of the rig on one wavefront.  The system (n <= 64) is built and Jacobi-
+// scaled in LDS (camcal_rig.h: rig_solve_build / rig_solve_scale); the Cholesky
+// factorisation then runs with row i of the matrix in lane i's registers: the pivot and
+// the column entries l_jk a trailing update needs are v_readlane broadcasts with constant
+// lane and register numbers (the loops are fully unrolled), so a step costs no LDS round
+// trip and no barrier (202 -> 73 us at n = 50).  Rows / columns beyond n are identity padding.
+__device__ __forceinline__ double lane_bcast_c(double x, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
+                          __builtin_amdgcn_readlane(__double2loint(x), src));
+}
+
 __global__ __launch_bounds__(64) void k_rig_solve_reduced(int NI, int n_cams, const double* __restrict__ rec,
                                                           unsigned long long mask, double lam,
                                                           const double* __restrict__ intr_in,
@@ -1259,22 +1274,115 @@ __global__ __launch_bounds__(64) void k_rig_solve_reduced(int NI, int n_cams, co
                                                           double* __restrict__ intr_out, double* __restrict__ ext_out,
                                                           double* __restrict__ dG, double* __restrict__ stats) {
   __shared__ RigSolveWs w;
+  constexpr int N = RIG_MAXN;
   const int lane = threadIdx.x, n = n_cams * (NI + 6);
-  rig_solve_build(lane, 64, NI, n_cams, rec, mask, lam, w);
+  // the entries of rig_solve_build, one per lane and trip (coalesced reads of C, several in flight)
+  {
+    const int G = NI + 6;
+    const int NU = NI * (NI + 1) / 2, NV = NU + NI + 1, NX = NI * 6 + 27;
+    const double* Cm = rec + (long long)n_cams * (NV + NX);
+    const double* d = Cm + (long long)n * n;
+#pragma unroll 4
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const int c = i / G, a = i - c * G, cj = j / G, b = j - cj * G;
+      const double* glob = rec + (long long)c * (NV + NX);
+      const double* rx = glob + NV;
+      double v;
+      if (!((mask >> i) & 1ull) || !((mask >> j) & 1ull)) {
+        v = (i == j) ? 1.0 : 0.0;
+      } else {
+        v = 0.0;
+        if (c == cj) {
+          const int lo = a < b ? a : b, hi = a < b ? b : a;
+          if (hi < NI) v = glob[tri(NI, lo, hi)];
+          else if (lo < NI) v = rx[lo * 6 + (hi - NI)];
+          else v = rx[NI * 6 + tri(6, lo - NI, hi - NI)];
+          if (i == j) v *= 1.0 + lam;
+        }
+        v -= Cm[e];
+      }
+      w.A[i * RIG_LD + j] = v;
+    }
+    __syncthreads();
+    if (lane < n) {
+      const int c = lane / G, a = lane - c * G;
+      const double* glob = rec + (long long)c * (NV + NX);
+      const double* rx = glob + NV;
+      double r = 0.0;
+      if ((mask >> lane) & 1ull) r = (a < NI ? glob[NU + a] : rx[NI * 6 + 21 + (a - NI)]) - d[lane];
+      w.rhs[lane] = r;
+      const double dii = w.A[lane * RIG_LD + lane];
+      w.sc[lane] = dii > 0.0 ? 1.0 / sqrt(dii) : 1.0;
+    }
+    if (lane == 0) w.ok = 1;
+  }
   __syncthreads();
   rig_solve_scale(lane, 64, n, w);
   __syncthreads();
-  for (int k = 0; k < n; ++k) {
-    rig_solve_chol_col(lane, 64, n, k, w);
-    __syncthreads();
-    rig_solve_chol_diag(lane, n, k, w);
-    rig_solve_chol_update(lane, 64, n, k, w);
-    __syncthreads();
+  double row[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) row[j] = (lane < n && j < n) ? w.A[lane * RIG_LD + j] : (lane == j ? 1.0 : 0.0);
+  double y = lane < n ? w.rhs[lane] : 0.0;
+  double my_inv = 1.0;               // 1 / L_ii of this lane's row
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {                     // uniform
+      const double p = lane_bcast_c(row[k], k);
+      const bool good = p > 0.0;
+      double rt;
+      const double rs = fast_rsqrt(good ? p : 1.0, rt);          // 1/sqrt(p) and sqrt(p), <= 2 ulp
+      const double inv = good ? rs : 0.0;
+      ok = ok && good;
+      const double lik = lane > k ? row[k] * inv : 0.0;          // column k of L below the diagonal
+      if (lane > k) row[k] = lik;
+      if (lane == k) { row[k] = good ? rt : 1.0; my_inv = good ? inv : 1.0; }
+#pragma unroll
+      for (int j = k + 1; j < N; ++j) row[j] = fma(-lik, lane_bcast_c(lik, j), row[j]);   // A_ij -= l_ik l_jk
+    }
   }
-  if (lane == 0) {
-    rig_solve_substitute(n, w);
-    rig_solve_finish(NI, n_cams, mask, w, intr_in, ext_in, intr_out, ext_out, dG, stats);
+  // L y = rhs, column by column
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {
+      const double yk = lane_bcast_c(y, k) * lane_bcast_c(my_inv, k);
+      if (lane == k) y = yk;
+      if (lane > k) y = fma(-row[k], yk, y);
+    }
   }
+  // L^T x = y needs the columns of L: transpose through LDS
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j) w.A[lane * RIG_LD + j] = row[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j) row[j] = w.A[j * RIG_LD + lane];   // row[j] = L_j,lane
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    if (k < n) {
+      const double xk = lane_bcast_c(y, k) * lane_bcast_c(my_inv, k);
+      if (lane == k) y = xk;
+      if (lane < k) y = fma(-row[k], xk, y);
+    }
+  }
+  // rig_solve_finish, one parameter per lane: out = in - dG, stats = [||dG||^2, ||globals_in||^2];
+  // a failed factorisation gives NaN so that the LM driver rejects the step
+  double s0 = 0.0, s1 = 0.0;
+  if (lane < n) {
+    const int G = NI + 6, c = lane / G, a = lane - c * G;
+    const double bad = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+    const double dx = ((mask >> lane) & 1ull) ? y * w.sc[lane] + bad : 0.0;
+    dG[lane] = dx;
+    const double prev = a < NI ? intr_in[c * 16 + a] : ext_in[c * 6 + (a - NI)];
+    if (a < NI) intr_out[c * 16 + a] = prev - dx;
+    else ext_out[c * 6 + (a - NI)] = prev - dx;
+    s0 = dx * dx;
+    s1 = prev * prev;
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) { stats[0] = s0; stats[1] = s1; }
 }
 
 inline int grid_tiles(const camcal_tiles* t) { return (t->n_tiles + WPB - 1) / WPB; }
@@ -1697,9 +1805,6 @@ int camcal_rig_assemble(int model, const camcal_tiles* tiles, const int32_t* slo
   const int ni = camcal_n_intr(model);
   if (ni < 0) return ni;
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemsetAsync(Vp, 0, sizeof(double) * 21 * P, s));
-  HIP_TRY(hipMemsetAsync(gp, 0, sizeof(double) * 6 * P, s));
-  HIP_TRY(hipMemsetAsync(Wp, 0, sizeof(double) * (ni + 6) * 6 * P, s));
   const int gp_ = grid_persistent(tiles);
   if (ni == 9) hipLaunchKernelGGL(k_rig_assemble<9>, dim3(gp_), dim3(TPB), 0, s, tiles->n_slots, tiles->n_tiles, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, scratch);
   else hipLaunchKernelGGL(k_rig_assemble<8>, dim3(gp_), dim3(TPB), 0, s, tiles->n_slots, tiles->n_tiles, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, scratch);
@@ -1714,7 +1819,8 @@ int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp_all
   const int ni = camcal_n_intr(model);
   if (ni < 0) return ni;
   if (n_cams <= 0 || P <= 0 || !Vp_all || !gp_all || !Wp_all || !Y || !z) return CAMCAL_E_BADARG;
-  const dim3 gr((unsigned)((P + TPB - 1) / TPB)), b(TPB);
+  const int n_cols = n_cams * (ni + 6);
+  const dim3 gr((unsigned)((P + TPB - 1) / TPB), (unsigned)((n_cols + RIG_SCHUR_CHUNK - 1) / RIG_SCHUR_CHUNK)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   if (ni == 9) hipLaunchKernelGGL(k_rig_pose_schur<15>, gr, b, 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, Y, z);
   else hipLaunchKernelGGL(k_rig_pose_schur<14>, gr, b, 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, Y, z);

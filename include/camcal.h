@@ -238,8 +238,10 @@ int camcal_rig_local_blocks(int model, const camcal_tiles* tiles, const double* 
                             double* scratch, void* stream);
 
 /* chain rule to the rig parameters for one camera: per board pose Vp [21][P],
- * gp [6][P], Wp [(NI+6)*6][P] (rows: intrinsics then extrinsics; zero where the
- * camera does not see the pose) and rec_ext = [U_ie (NI*6) | U_ee (21) | b_e (6)] */
+ * gp [6][P], Wp [(NI+6)*6][P] (rows: intrinsics then extrinsics) and rec_ext =
+ * [U_ie (NI*6) | U_ee (21) | b_e (6)].  Only the poses this camera sees are written:
+ * the caller zeroes Vp, gp, Wp ONCE (which poses a camera sees never changes), so the
+ * entries of unseen poses stay zero through every evaluation. */
 int camcal_rig_assemble(int model, const camcal_tiles* tiles, const int32_t* slot_pose,
                         const double* rig_pose, int64_t P, const double* ext, const double* V,
                         const double* W, const double* g, double* Vp, double* gp, double* Wp,

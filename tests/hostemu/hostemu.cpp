@@ -192,9 +192,6 @@ void rig_assemble(const camcal_tiles* t, const int32_t* slot_pose, const double*
   const int64_t S = t->n_slots;
   double acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  std::memset(Vp, 0, sizeof(double) * 21 * P);
-  std::memset(gp, 0, sizeof(double) * 6 * P);
-  std::memset(Wp, 0, sizeof(double) * (NI + 6) * 6 * P);
   for (int64_t slot = 0; slot < S; ++slot) {
     const int idx = slot_pose[slot];
     if (idx < 0) continue;
