@@ -546,7 +546,10 @@ CC_HD void w_to_rodrigues_frame(const double Jl[9], double* W) {
 
 // In-place Cholesky of a 6x6 SPD matrix stored as upper triangle (21): on
 // return V holds U with V = U^T U.  Returns false if a pivot is not positive.
-CC_HD bool chol6(double V[21]) {
+// inv_diag receives 1 / U_ii: the elimination substitutes NI + 1 vectors through one
+// factor, and the six reciprocals the factorisation computes anyway replace 6 (NI + 1)
+// divisions.  Square root and reciprocal come from one hardware-seeded rsqrt (<= 2 ulp).
+CC_HD bool chol6(double V[21], double inv_diag[6]) {
   bool ok = true;
   CC_UNROLL
   for (int i = 0; i < 6; ++i) {
@@ -554,8 +557,9 @@ CC_HD bool chol6(double V[21]) {
     CC_UNROLL
     for (int k = 0; k < i; ++k) d -= V[tri(6, k, i)] * V[tri(6, k, i)];
     ok = ok && (d > 0.0);
-    const double u = sqrt(d > 0.0 ? d : 1.0);
-    const double iu = 1.0 / u;
+    double u;
+    const double iu = fast_rsqrt(d > 0.0 ? d : 1.0, u);
+    inv_diag[i] = iu;
     V[tri(6, i, i)] = u;
     CC_UNROLL
     for (int j = i + 1; j < 6; ++j) {
@@ -567,13 +571,9 @@ CC_HD bool chol6(double V[21]) {
   }
   return ok;
 }
-// The same, also returning 1 / U_ii: the elimination substitutes NI + 1 vectors through
-// one factor, and six reciprocals replace 6 (NI + 1) divisions.
-CC_HD bool chol6(double V[21], double inv_diag[6]) {
-  const bool ok = chol6(V);
-  CC_UNROLL
-  for (int i = 0; i < 6; ++i) inv_diag[i] = 1.0 / V[tri(6, i, i)];
-  return ok;
+CC_HD bool chol6(double V[21]) {
+  double inv_diag[6];
+  return chol6(V, inv_diag);
 }
 CC_HD void chol6_fwd(const double U[21], const double inv_diag[6], double y[6]) {
   CC_UNROLL
