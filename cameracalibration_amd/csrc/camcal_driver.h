@@ -7,16 +7,21 @@
 //
 // Included by camcal_kernels.hip and by the tests' CPU lane emulator; the
 // includer provides
-//   int camcal_read_back(double* dst_host, const double* src, int n, void* stream)
+//   int camcal_read_begin(const double* src, int n, int offset, void* stream)
+//   int camcal_read_end(double* dst_host, int n_total)
 //   int camcal_copy_doubles(double* dst, const double* src, int n, void* stream)
-// (device -> host with a stream synchronisation; device -> device on the stream).
+// (read_begin: asynchronous copy of n doubles to position `offset` of a per-thread landing
+// buffer, ordered on the stream; read_end: wait for the LAST begin and hand out the first
+// n_total doubles -- work enqueued after the begin keeps running meanwhile;
+// copy_doubles: device -> device on the stream).
 #pragma once
 #include <cmath>
 #include <cstdint>
 
 #include "../../include/camcal.h"
 
-int camcal_read_back(double* dst_host, const double* src, int n, void* stream);
+int camcal_read_begin(const double* src, int n, int offset, void* stream);
+int camcal_read_end(double* dst_host, int n_total);
 int camcal_copy_doubles(double* dst, const double* src, int n, void* stream);
 
 #define CAMCAL_DRV_TRY(x)      \
@@ -47,14 +52,17 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
     CAMCAL_DRV_TRY(camcal_solve_reduced(CAMCAL_FISHEYE, rec, rec + ng, mask_host, 0.0, -alpha2, intr, intr, dK,
                                         stats, stream));
     double st[5];
-    CAMCAL_DRV_TRY(camcal_read_back(st, stats, 5, stream));
-    change = std::sqrt(st[2]) / std::sqrt(st[3]);
+    CAMCAL_DRV_TRY(camcal_read_begin(stats, 5, 0, stream));
+    // cv2 re-estimates the poses before it looks at `change`: the launch does not wait for the host
     if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
+    CAMCAL_DRV_TRY(camcal_read_end(st, 5));
+    change = std::sqrt(st[2]) / std::sqrt(st[3]);
     ++it;
   }
   CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
                                     stream));
-  CAMCAL_DRV_TRY(camcal_read_back(cost_out_host, rec + ng - 1, 1, stream));
+  CAMCAL_DRV_TRY(camcal_read_begin(rec + ng - 1, 1, 0, stream));
+  CAMCAL_DRV_TRY(camcal_read_end(cost_out_host, 1));
   *iterations_out_host = it;
   return 0;
 }
@@ -80,7 +88,8 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
   CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[cur], pose2[cur], 1, glob, nullptr, V2[cur], g2[cur], scratch,
                                     stream));
   double err = 0.0;
-  CAMCAL_DRV_TRY(camcal_read_back(&err, glob + ng - 1, 1, stream));
+  CAMCAL_DRV_TRY(camcal_read_begin(glob + ng - 1, 1, 0, stream));
+  CAMCAL_DRV_TRY(camcal_read_end(&err, 1));
   for (;;) {
     const int tri = 1 - cur;
     const double prev_err = err;
@@ -95,9 +104,14 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
       CAMCAL_DRV_TRY(camcal_backsub(M, tiles, V2[cur], W, g2[cur], lam, dK, pose2[cur], pose2[tri], norms, scratch, stream));
       CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[tri], pose2[tri], 1, glob_trial, nullptr, V2[tri], g2[tri],
                                         scratch, stream));
-      CAMCAL_DRV_TRY(camcal_read_back(st, stats, 5, stream));
-      CAMCAL_DRV_TRY(camcal_read_back(nr, norms, 2, stream));
-      CAMCAL_DRV_TRY(camcal_read_back(&err, glob_trial + ng - 1, 1, stream));
+      double back[8];                              // one wait for the three small records
+      CAMCAL_DRV_TRY(camcal_read_begin(stats, 5, 0, stream));
+      CAMCAL_DRV_TRY(camcal_read_begin(norms, 2, 5, stream));
+      CAMCAL_DRV_TRY(camcal_read_begin(glob_trial + ng - 1, 1, 7, stream));
+      CAMCAL_DRV_TRY(camcal_read_end(back, 8));
+      for (int i = 0; i < 5; ++i) st[i] = back[i];
+      nr[0] = back[5]; nr[1] = back[6];
+      err = back[7];
       if (!(err > prev_err)) break;
       ++lam_lg10;
       if (lam_lg10 > 16) break;

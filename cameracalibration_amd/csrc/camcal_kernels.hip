@@ -1977,16 +1977,47 @@ int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream
 
 // ---------------------------------------------------------------------------
 // Host-side solver loops (camcal_driver.h) and their two memory helpers.
-int camcal_read_back(double* dst_host, const double* src, int n, void* stream) {
-  // a small pinned landing buffer per host thread: the copy is a plain DMA, no staging
-  static thread_local double* pinned = nullptr;
-  constexpr int CAP = 64;
-  if (n <= 0 || n > CAP || !dst_host || !src) return CAMCAL_E_BADARG;
-  if (!pinned) HIP_TRY(hipHostMalloc((void**)&pinned, CAP * sizeof(double), hipHostMallocPortable));
+namespace {
+// a small pinned landing buffer and an event per host thread: the copies are plain DMAs
+// (no staging), and waiting on the event instead of the stream lets kernels launched after
+// camcal_read_begin run while the host reads
+constexpr int READ_CAP = 64;
+struct ReadBack {
+  double* pinned = nullptr;
+  hipEvent_t ev = nullptr;
+  int dev = -1;                      // device the event belongs to
+};
+thread_local ReadBack g_rb;
+int read_back_init() {
+  if (!g_rb.pinned) HIP_TRY(hipHostMalloc((void**)&g_rb.pinned, READ_CAP * sizeof(double), hipHostMallocPortable));
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (g_rb.ev && g_rb.dev != dev) {  // the calling thread moved to another device
+    (void)hipEventDestroy(g_rb.ev);
+    g_rb.ev = nullptr;
+  }
+  if (!g_rb.ev) {
+    HIP_TRY(hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming));
+    g_rb.dev = dev;
+  }
+  return 0;
+}
+}  // namespace
+
+int camcal_read_begin(const double* src, int n, int offset, void* stream) {
+  if (n <= 0 || offset < 0 || offset + n > READ_CAP || !src) return CAMCAL_E_BADARG;
+  const int rc = read_back_init();
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(pinned, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  for (int i = 0; i < n; ++i) dst_host[i] = pinned[i];
+  HIP_TRY(hipMemcpyAsync(g_rb.pinned + offset, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipEventRecord(g_rb.ev, s));
+  return 0;
+}
+
+int camcal_read_end(double* dst_host, int n_total) {
+  if (n_total <= 0 || n_total > READ_CAP || !dst_host || !g_rb.ev) return CAMCAL_E_BADARG;
+  HIP_TRY(hipEventSynchronize(g_rb.ev));
+  for (int i = 0; i < n_total; ++i) dst_host[i] = g_rb.pinned[i];
   return 0;
 }
 

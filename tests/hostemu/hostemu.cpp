@@ -533,9 +533,15 @@ int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 
 
 // Host-side solver loops: the same sequencing code as the HIP library, over this emulator's stages.
 #include <cstring>
-int camcal_read_back(double* dst_host, const double* src, int n, void*) {
-  if (n <= 0 || !dst_host || !src) return CAMCAL_E_BADARG;
-  std::memcpy(dst_host, src, (size_t)n * sizeof(double));
+static thread_local double g_landing[64];
+int camcal_read_begin(const double* src, int n, int offset, void*) {
+  if (n <= 0 || offset < 0 || offset + n > 64 || !src) return CAMCAL_E_BADARG;
+  std::memcpy(g_landing + offset, src, (size_t)n * sizeof(double));
+  return 0;
+}
+int camcal_read_end(double* dst_host, int n_total) {
+  if (n_total <= 0 || n_total > 64 || !dst_host) return CAMCAL_E_BADARG;
+  std::memcpy(dst_host, g_landing, (size_t)n_total * sizeof(double));
   return 0;
 }
 int camcal_copy_doubles(double* dst, const double* src, int n, void*) {
