@@ -122,8 +122,14 @@ def _gather_views(object_points, image_points, min_points=4):
             raise error("number of object and image points must be equal in every view")
         if np.any(counts < min_points):
             raise error("every view needs at least %d points" % min_points)
-        objs = [np.concatenate([o.ravel() for o in object_points]).astype(np.float32, copy=False).reshape(-1, 3)]
-        imgs = [np.concatenate([i.ravel() for i in image_points]).astype(np.float32, copy=False).reshape(-1, 2)]
+        try:                                   # equal trailing shapes ((n,1,3) / (n,3)): one C call each
+            cat_o = np.concatenate(object_points, axis=0)
+            cat_i = np.concatenate(image_points, axis=0)
+        except ValueError:                     # mixed layouts: flatten per view
+            cat_o = np.concatenate([o.ravel() for o in object_points])
+            cat_i = np.concatenate([i.ravel() for i in image_points])
+        objs = [cat_o.astype(np.float32, copy=False).reshape(-1, 3)]
+        imgs = [cat_i.astype(np.float32, copy=False).reshape(-1, 2)]
     else:
         objs, imgs, counts = [], [], []
         for o, i in zip(object_points, image_points):

@@ -102,8 +102,7 @@ class Engine:
             raise ValueError("view_ptr does not match the point arrays")
         self._call("camcal_pack_tiles", t_obj.data_ptr(), t_img.data_ptr(), t_vp.data_ptr(),
                    self.t_slot_view.data_ptr(), C.byref(self.tiles), self.t_pts.data_ptr(), self._stream())
-        self._sync()
-        del t_obj, t_img, t_vp
+        del t_obj, t_img, t_vp        # stream-ordered: the allocator reuses them only behind the pack
         # solver buffers: one zeroed allocation, carved up (every piece a multiple of 8 bytes)
         NI = self.NI
         sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
