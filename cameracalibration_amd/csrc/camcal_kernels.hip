@@ -1078,12 +1078,15 @@ __global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __re
   }
 }
 
+// blockIdx.x = tile, the PACK_SPLIT * WPB wavefronts of a tile take its corners in turn:
+// a lane reads one point of its view (12 + 8 bytes, strided by view) and the wavefront
+// writes five coalesced 256-byte rows
+constexpr int PACK_SPLIT = 8;
 __global__ __launch_bounds__(TPB) void k_pack_tiles(const float* __restrict__ obj, const float* __restrict__ img,
                                                     const int64_t* __restrict__ view_ptr,
                                                     const int32_t* __restrict__ slot_view, camcal_tiles t,
                                                     float* __restrict__ out) {
-  const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
-  if (tile >= t.n_tiles) return;
+  const int tile = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int64_t slot = (int64_t)tile * LANES + lane;
   const int v = slot_view[slot];
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(TPB) void k_pack_tiles(const float* __restrict__ ob
   const int nmax = t.tile_nmax[tile];
   const int64_t p0 = v >= 0 ? view_ptr[v] : 0;
   float* base = out + t.tile_off[tile] + lane;
-  for (int k = 0; k < nmax; ++k) {
+  for (int k = blockIdx.y * WPB + (threadIdx.x >> 6); k < nmax; k += PACK_SPLIT * WPB) {
     float X = 0, Y = 0, Z = 0, u = 0, w = 0;
     if (k < n) {
       const float* o = obj + (p0 + k) * 3;
@@ -1465,7 +1468,7 @@ int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, 
 int camcal_pack_tiles(const float* obj_xyz, const float* img_uv, const int64_t* view_ptr,
                       const int32_t* slot_view, const camcal_tiles* tiles, float* pts_out, void* stream) {
   if (!tiles_ok(tiles) || !obj_xyz || !img_uv || !view_ptr || !slot_view || !pts_out) return CAMCAL_E_BADARG;
-  hipLaunchKernelGGL(k_pack_tiles, dim3(grid_tiles(tiles)), dim3(TPB), 0, (hipStream_t)stream, obj_xyz, img_uv,
+  hipLaunchKernelGGL(k_pack_tiles, dim3(tiles->n_tiles, PACK_SPLIT), dim3(TPB), 0, (hipStream_t)stream, obj_xyz, img_uv,
                      view_ptr, slot_view, *tiles, pts_out);
   HIP_TRY(hipGetLastError());
   return 0;
