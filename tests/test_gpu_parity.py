@@ -193,6 +193,32 @@ def test_library_sequenced_loops_equal_the_python_loops_on_gpu(dev):
         assert np.array_equal(np.hstack(a[3]), np.hstack(b[3]))
 
 
+@pytest.mark.parametrize("nv", [1, 63, 65, 2048, 2049, 8192, 8193])
+def test_automatic_mapping_at_its_size_boundaries(dev, nv):
+    """The mapping chosen by size (64 lanes per view up to 32 tiles, 16 up to 128, one above)
+    against one lane per view, on ragged sets either side of every boundary: the single-pass
+    record, the stored blocks and a pose re-estimation."""
+    lib = _lib.load()
+    P = synth.config("C3", n_views=nv)
+    out = []
+    for mode in (1, -1):
+        lib.check(lib.camcal_set_lanes_per_view(mode), "camcal_set_lanes_per_view")
+        try:
+            E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+            E.set_intr(0, P.intr_guess())
+            E.set_poses(0, P.poses_true.numpy())
+            E.normal_eq(0, 0, 1e-3, store_blocks=True, fused=True)
+            rec, W = E.rec.cpu().numpy().copy(), E.slots_to_views(E.W.T).copy()
+            E.pose_refine(0, 0, 20, 1e-10)
+            out.append((rec, W, E.get_poses(0), E.slots_to_views(E.iters).copy()))
+        finally:
+            lib.check(lib.camcal_set_lanes_per_view(-1), "camcal_set_lanes_per_view")
+    (r1, w1, p1, i1), (r2, w2, p2, i2) = out
+    assert np.abs(r1 - r2).max() <= 1e-11 * np.abs(r1).max()
+    assert np.abs(w1 - w2).max() <= 1e-11 * np.abs(w1).max()
+    assert np.allclose(p1, p2, rtol=1e-9, atol=1e-9) and (i1 == i2).mean() > 0.98
+
+
 def test_noise_free_ground_truth_on_gpu(dev):
     P = synth.config("C2", n_views=300, noise=0.0)
     objs, imgs = P.as_lists()
