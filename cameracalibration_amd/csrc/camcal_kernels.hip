@@ -61,6 +61,20 @@ __device__ __forceinline__ double wave_sum(double x) {
 // OFF = 32 and 16 are single gfx950 instructions per dword (v_permlane32_swap: the upper
 // half of the first operand <-> the lower half of the second; v_permlane16_swap: odd rows
 // <-> even rows); the others go through the LDS crossbar (ds_bpermute).
+// Partner of a lane for the steps inside a row of 16 lanes, as DPP moves (VALU, no LDS
+// crossbar).  The partner only has to differ in bit OFF and the four pairings together
+// have to connect the 16 lanes: 15 - i (row_mirror) for OFF = 8, 7 - i within each half
+// row (row_half_mirror) for OFF = 4, i ^ 2 and i ^ 1 (quad_perm) for OFF = 2 and 1.
+template <int OFF>
+__device__ __forceinline__ double row_partner(double x) {
+  static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "row-local steps only");
+  constexpr int ctrl = OFF == 8 ? 0x140 : OFF == 4 ? 0x141 : OFF == 2 ? 0x4E : 0xB1;
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int plo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
+  const int phi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+  return __hiloint2double(phi, plo);
+}
+
 template <int OFF>
 __device__ __forceinline__ double pair_exchange_sum(double a, double b, bool up) {
   if constexpr (OFF == 32 || OFF == 16) {
@@ -77,7 +91,7 @@ __device__ __forceinline__ double pair_exchange_sum(double a, double b, bool up)
     }
   } else {
     const double send = up ? a : b, keep = up ? b : a;
-    return keep + __shfl_xor(send, OFF, 64);
+    return keep + row_partner<OFF>(send);
   }
 }
 
@@ -99,7 +113,7 @@ __device__ __forceinline__ void pair_exchange_gather(double own, bool up, double
       b = __hiloint2double((int)h[1], (int)l[1]);
     }
   } else {
-    const double got = __shfl_xor(own, OFF, 64);
+    const double got = row_partner<OFF>(own);
     a = up ? got : own;
     b = up ? own : got;
   }
