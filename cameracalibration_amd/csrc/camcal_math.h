@@ -168,39 +168,85 @@ CC_HD double tan_acute(double x) {
 }
 
 // ---------------------------------------------------------------------------
-// Rodrigues vector -> rotation matrix (row-major), as cvRodrigues2.
-CC_HD void rodrigues(const double r[3], double R[9]) {
-  const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-  const double th = sqrt(th2);
-  if (th < 2.220446049250313e-16) {
-    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+// The three SO(3) series of a rotation vector with theta^2 = t:
+//   A = sin(theta)/theta, B = (1 - cos theta)/theta^2, C = (theta - sin theta)/theta^3.
+// Below theta = 0.5 their Taylor series; above, sin and cos of theta/2 from the Taylor
+// series on |y| <= pi/4 (as tan_acute), sin theta = 2 sh ch and 1 - cos theta = 2 sh^2
+// (no cancellation), so one reduction serves the rotation matrix and the left Jacobian of
+// the same vector (the compiler merges the two evaluations).  Rotation vectors longer than
+// 4.7 (1.5 pi; none occurs for a board in front of a camera) take the libm route.
+CC_HD void so3_series(double t, double& A, double& B, double& C) {
+  if (t < 0.25) {
+    A = 1.0 + t * (-1.0 / 6 + t * (1.0 / 120 + t * (-1.0 / 5040 + t * (1.0 / 362880 + t * (-1.0 / 39916800 +
+        t * (1.0 / 6227020800.0))))));
+    B = 0.5 + t * (-1.0 / 24 + t * (1.0 / 720 + t * (-1.0 / 40320 + t * (1.0 / 3628800 +
+        t * (-1.0 / 479001600 + t * (1.0 / 87178291200.0))))));
+    C = 1.0 / 6 + t * (-1.0 / 120 + t * (1.0 / 5040 + t * (-1.0 / 362880 + t * (1.0 / 39916800 +
+        t * (-1.0 / 6227020800.0 + t * (1.0 / 1307674368000.0))))));
     return;
   }
-  const double s = sin(th), c = cos(th), c1 = 1.0 - c, it = 1.0 / th;
-  const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
-  R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
-  R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
-  R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+  double th;
+  const double ith = fast_rsqrt(t, th);          // 1/theta, theta
+  double sn, omc;                                // sin theta, 1 - cos theta
+  const double h = 0.5 * th;
+  if (h <= 2.35) {
+    const bool big = h > 0.78539816339744831;
+    const double y = big ? (1.5707963267948966 - h) + 6.123233995736766e-17 : h;
+    const double z = y * y;
+    double sp = -8.2206352466243297e-18;
+    sp = fma(sp, z, 2.8114572543455208e-15);
+    sp = fma(sp, z, -7.6471637318198165e-13);
+    sp = fma(sp, z, 1.6059043836821615e-10);
+    sp = fma(sp, z, -2.5052108385441719e-08);
+    sp = fma(sp, z, 2.7557319223985891e-06);
+    sp = fma(sp, z, -1.9841269841269841e-04);
+    sp = fma(sp, z, 8.3333333333333333e-03);
+    sp = fma(sp, z, -1.6666666666666667e-01);
+    const double sy = fma(y * z, sp, y);
+    double cp = 4.1103176233121649e-19;
+    cp = fma(cp, z, -1.5619206968586226e-16);
+    cp = fma(cp, z, 4.7794773323873853e-14);
+    cp = fma(cp, z, -1.1470745597729725e-11);
+    cp = fma(cp, z, 2.0876756987868099e-09);
+    cp = fma(cp, z, -2.7557319223985891e-07);
+    cp = fma(cp, z, 2.4801587301587302e-05);
+    cp = fma(cp, z, -1.3888888888888889e-03);
+    cp = fma(cp, z, 4.1666666666666667e-02);
+    cp = fma(cp, z, -0.5);
+    const double cy = fma(cp, z, 1.0);
+    const double sh = big ? cy : sy, ch = big ? sy : cy;     // sin, cos of theta / 2
+    sn = 2.0 * sh * ch;
+    omc = 2.0 * sh * sh;
+  } else {
+    sn = sin(th);
+    const double sh = sin(h);
+    omc = 2.0 * sh * sh;
+  }
+  const double it2 = ith * ith;
+  A = sn * ith;
+  B = omc * it2;
+  C = (th - sn) * it2 * ith;
+}
+
+// Rodrigues vector -> rotation matrix (row-major), as cvRodrigues2:
+// R = cos I + (1 - cos) n n^T + sin [n]x = I + A [r]x + B [r]x^2.
+CC_HD void rodrigues(const double r[3], double R[9]) {
+  const double x = r[0], y = r[1], z = r[2];
+  const double th2 = x * x + y * y + z * z;
+  double A, B, C;
+  so3_series(th2, A, B, C);
+  // [r]x^2 = r r^T - th2 I
+  R[0] = 1.0 + B * (x * x - th2); R[1] = -A * z + B * x * y;        R[2] = A * y + B * x * z;
+  R[3] = A * z + B * x * y;       R[4] = 1.0 + B * (y * y - th2);   R[5] = -A * x + B * y * z;
+  R[6] = -A * y + B * x * z;      R[7] = A * x + B * y * z;         R[8] = 1.0 + B * (z * z - th2);
 }
 
 // SO(3) left Jacobian Jl(r) = I + B [r]x + C [r]x^2 (row-major).
 CC_HD void left_jacobian(const double r[3], double J[9]) {
-  const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-  double B, C;
-  if (th2 < 0.25) {
-    // series: B = (1-cos t)/t^2, C = (t - sin t)/t^3
-    B = 0.5 + th2 * (-1.0 / 24 + th2 * (1.0 / 720 + th2 * (-1.0 / 40320 + th2 * (1.0 / 3628800 +
-        th2 * (-1.0 / 479001600 + th2 * (1.0 / 87178291200.0))))));
-    C = 1.0 / 6 + th2 * (-1.0 / 120 + th2 * (1.0 / 5040 + th2 * (-1.0 / 362880 + th2 * (1.0 / 39916800 +
-        th2 * (-1.0 / 6227020800.0 + th2 * (1.0 / 1307674368000.0))))));
-  } else {
-    const double th = sqrt(th2);
-    const double sh = sin(0.5 * th);
-    B = 2.0 * sh * sh / th2;
-    C = (th - sin(th)) / (th2 * th);
-  }
   const double x = r[0], y = r[1], z = r[2];
-  // [r]x^2 = r r^T - th2 I
+  const double th2 = x * x + y * y + z * z;
+  double A, B, C;
+  so3_series(th2, A, B, C);
   J[0] = 1.0 + C * (x * x - th2); J[1] = -B * z + C * x * y;        J[2] = B * y + C * x * z;
   J[3] = B * z + C * x * y;       J[4] = 1.0 + C * (y * y - th2);   J[5] = -B * x + C * y * z;
   J[6] = -B * y + C * x * z;      J[7] = B * x + C * y * z;         J[8] = 1.0 + C * (z * z - th2);
