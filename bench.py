@@ -169,8 +169,10 @@ def solve_times(dev, with_cpu=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults long enough to get past the device's clock ramp: the first ~25 launches after the set-up
+    # kernels run up to 17 % slower than the steady state (profiles/README.md, r01_i)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--views", type=int, default=1_000_000, help="views per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solves", action="store_true", help="skip the whole-solve wall-clock extras")
