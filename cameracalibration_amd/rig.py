@@ -217,34 +217,34 @@ class RigEngine:
         of T_pc o T_pk^-1 over shared poses, board poses from the
         lowest-numbered camera that sees them.  Writes buffer 0."""
         nC, P = self.n_cams, self.P
-        Rpc = torch.zeros(nC, P, 3, 3, dtype=torch.float64)
-        tpc = torch.zeros(nC, P, 3, dtype=torch.float64)
-        vis = torch.zeros(nC, P, dtype=torch.bool)
+        dv = self.device                  # the batched 3x3 algebra stays where the poses are
+        f64 = dict(dtype=torch.float64, device=dv)
+        Rpc = torch.zeros(nC, P, 3, 3, **f64)
+        tpc = torch.zeros(nC, P, 3, **f64)
+        vis = torch.zeros(nC, P, dtype=torch.bool, device=dv)
         for c, e in enumerate(self.E):
             e.intr[0].copy_(self.intr[0][c])
             e.pose_init(0, 0)
             e.pose_refine(0, 0, 20, 1e-10)
-            sp = self.slot_pose[c].cpu()
+            sp = self.slot_pose[c]
             ok = sp >= 0
-            pose = e.pose[0].cpu().t()[ok]
+            pose = e.pose[0].t()[ok]
             idx = sp[ok].long()
             Rpc[c, idx] = _rot_from_rvec(pose[:, :3])
             tpc[c, idx] = pose[:, 3:]
             vis[c, idx] = True
-        sums = torch.zeros(nC, nC, 13, dtype=torch.float64)
+        sums = torch.zeros(nC, nC, 13, **f64)
         for c in range(nC):
             for k in range(nC):
                 if c == k:
                     continue
-                both = vis[c] & vis[k]
-                if not both.any():
-                    continue
-                Rck = Rpc[c, both] @ Rpc[k, both].transpose(1, 2)
-                tck = tpc[c, both] - torch.einsum("pij,pj->pi", Rck, tpc[k, both])
-                sums[c, k, :9] = Rck.sum(0).reshape(-1)
-                sums[c, k, 9:12] = tck.sum(0)
-                sums[c, k, 12] = float(both.sum())
-        sums = comm.allreduce(sums.to(self.device)).cpu()
+                both = (vis[c] & vis[k]).to(torch.float64)           # weights instead of a gather
+                Rck = Rpc[c] @ Rpc[k].transpose(1, 2)
+                tck = tpc[c] - torch.einsum("pij,pj->pi", Rck, tpc[k])
+                sums[c, k, :9] = (Rck * both[:, None, None]).sum(0).reshape(-1)
+                sums[c, k, 9:12] = (tck * both[:, None]).sum(0)
+                sums[c, k, 12] = both.sum()
+        sums = comm.allreduce(sums).cpu()
         extR = {0: (torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64))}
         while len(extR) < nC:
             best = None
@@ -269,20 +269,24 @@ class RigEngine:
         for c in range(1, nC):
             ext[c, :3] = _rvec_from_rot(extR[c][0][None])[0]
             ext[c, 3:] = extR[c][1]
-        poses = torch.zeros(P, 6, dtype=torch.float64)
+        # board poses from the lowest-numbered camera that sees them: all candidates at once
+        first = torch.full((P,), nC, dtype=torch.long, device=dv)
+        for c in range(nC - 1, -1, -1):
+            first = torch.where(vis[c], torch.full_like(first, c), first)
+        Rall = torch.stack([extR[c][0] for c in range(nC)]).to(dv)      # (nC, 3, 3)
+        tall = torch.stack([extR[c][1] for c in range(nC)]).to(dv)      # (nC, 3)
+        seen = first < nC
+        cam = first.clamp_max(nC - 1)
+        ar = torch.arange(P, device=dv)
+        Rp = Rall[cam].transpose(1, 2) @ Rpc[cam, ar]                    # R_c^T R_pc
+        tp = torch.einsum("pji,pj->pi", Rall[cam], tpc[cam, ar] - tall[cam])   # R_c^T (t_pc - t_c)
+        poses = torch.zeros(P, 6, **f64)
         poses[:, 5] = 1.0
-        todo = torch.ones(P, dtype=torch.bool)
-        for c in range(nC):
-            sel = todo & vis[c]
-            if not sel.any():
-                continue
-            Rc, tc = extR[c]
-            Rp = Rc.t() @ Rpc[c, sel]
-            tp = (tpc[c, sel] - tc) @ Rc                       # R_c^T (t_pc - t_c)
-            poses[sel] = torch.cat([_rvec_from_rot(Rp), tp], dim=1)
-            todo &= ~sel
-        self.ext[0].copy_(ext.to(self.device))
-        self.rig_pose[0].copy_(poses.t().contiguous().to(self.device))
+        if bool(seen.any()):
+            cand = torch.cat([_rvec_from_rot(Rp), tp], dim=1)
+            poses = torch.where(seen[:, None], cand, poses)
+        self.ext[0].copy_(ext.to(dv))
+        self.rig_pose[0].copy_(poses.t().contiguous())
 
 
 def lm_rig(R, free, max_iter, eps, comm=None, log=None):
@@ -421,8 +425,9 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
     Ks = [np.array([[v[0], 0.0, v[2]], [0.0, v[1], v[3]], [0.0, 0.0, 1.0]]) for v in intr]
     Ds = [v[4:].reshape(-1, 1).copy() for v in intr]
     Ts = [(e[:3].reshape(3, 1).copy(), e[3:].reshape(3, 1).copy()) for e in ext]
-    rvecs = tuple(np.ascontiguousarray(p[:3].reshape(3, 1)) for p in poses)
-    tvecs = tuple(np.ascontiguousarray(p[3:].reshape(3, 1)) for p in poses)
+    npz = poses.shape[0]
+    rvecs = tuple(np.ascontiguousarray(poses[:, :3]).reshape(npz, 3, 1))
+    tvecs = tuple(np.ascontiguousarray(poses[:, 3:]).reshape(npz, 3, 1))
     if _info is not None:
         _info.update(iters=iters, log=log, engine=R, init=init_state, cost=err, n_obs=n_total)
     return rms, Ks, Ds, Ts, rvecs, tvecs
