@@ -107,8 +107,11 @@ class RigEngine:
         self.Y = torch.zeros(rows, self.nG, **f64)          # rows beyond 6P stay zero
         self.z = torch.zeros(rows, **f64)
         self.dG = torch.zeros(self.nG, **f64)
-        self.norms = torch.zeros(2, **f64)
-        self.gstats = torch.zeros(2, **f64)
+        self.small = torch.zeros(4, **f64)                   # [gstats | norms]: read back together
+        self.gstats = self.small[:2]
+        self.norms = self.small[2:]
+        self._cost_idx = torch.tensor([c * (self.NV + self.NX) + self.NV - 1 for c in range(nC)],
+                                      dtype=torch.long, device=dev)
         self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model, 1)), **f64)
         self._tri_i = torch.from_numpy(_tri_index(self.NI)).to(dev)
         self._tri_6 = torch.from_numpy(_tri_index(6)).to(dev)
@@ -172,7 +175,13 @@ class RigEngine:
         d.copy_(torch.matmul(Yt, self.z.view(-1, self.chunk, 1)).sum(0).view(-1))
 
     def cost(self, b):
-        return sum(self.cam_rec(b, c)[0][self.NV - 1] for c in range(self.n_cams))
+        return self.rec[b][self._cost_idx].sum()
+
+    def trial_scalars(self, b):
+        """(cost, [||dG||^2, ||globals||^2], [||d poses||^2, ||poses||^2]) of a trial step: one read-back."""
+        out = torch.cat([self.rec[b][self._cost_idx], self.small]).cpu().numpy()
+        n = self.n_cams
+        return float(out[:n].sum()), out[n:n + 2], out[n + 2:n + 4]
 
     def reduced_system(self, b, lam):
         """(M, rhs) over the n_cams*(NI+6) globals, diag(M) damped like CvLevMarq."""
@@ -301,7 +310,7 @@ def lm_rig(R, free, max_iter, eps, comm=None, log=None):
     cur, tri = 0, 1
     R.evaluate(cur)
     comm.allreduce(R.rec[cur][:R.rec_len])
-    err = float(R.cost(cur).item())
+    err = float(R.cost(cur).item()) if comm.enabled else R.trial_scalars(cur)[0]
     iters = 0
 
     def step(lam):
@@ -312,8 +321,10 @@ def lm_rig(R, free, max_iter, eps, comm=None, log=None):
         comm.allreduce(R.norms)
         R.evaluate(tri)
         comm.allreduce(R.rec[tri][:R.rec_len])
-        out = torch.cat([R.cost(tri).reshape(1), gn, R.norms]).cpu().numpy()
-        return float(out[0]), out[1:3], out[3:5]
+        if comm.enabled:
+            out = torch.cat([R.cost(tri).reshape(1), gn, R.norms]).cpu().numpy()
+            return float(out[0]), out[1:3], out[3:5]
+        return R.trial_scalars(tri)
 
     while True:
         prev_err = err
