@@ -200,6 +200,13 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     Supported: ``CALIB_USE_INTRINSIC_GUESS`` (required -- the only mode the
     reference uses) optionally with FIX_FOCAL_LENGTH / FIX_PRINCIPAL_POINT /
     ZERO_TANGENT_DIST / FIX_TANGENT_DIST / FIX_K1..K3.  Other model flags raise.
+
+    Keyword-only extras (tests, tools): ``_info`` -- a dict that receives
+    ``iters``, ``engine`` and ``log`` (the per-iteration records, collected only
+    when the dict holds ``log=True``: asking for them keeps the loop in
+    solver.py instead of the library); ``_comm`` -- a solver.Comm for a
+    multi-rank solve; ``_lib_override`` / ``_device_override`` -- the tests'
+    CPU lane emulator.
     """
     flags = int(flags)
     unsupported = (CALIB_FIX_ASPECT_RATIO | CALIB_RATIONAL_MODEL | CALIB_THIN_PRISM_MODEL |
