@@ -96,6 +96,34 @@ def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv, mapping)
         assert abs(nr[1] / (poses ** 2).sum() - 1) < 1e-12
 
 
+@pytest.mark.parametrize("name,nv", [("C2", 500), ("C3", 700)])
+def test_benchmarked_single_pass_record_matches_oracle(dev, name, nv, mapping):
+    """The instantiation bench.py times -- camcal_normal_eq_fused without block stores at
+    lambda = 0 (k_normal_fused<fisheye, no stores, planar>; cv2's ComputeJacobians + the
+    elimination inside solve(JJ2, ex3), camera_calib.py:74-77) -- record by record against
+    the oracle's blocks and their undamped Schur complement."""
+    P = synth.config(name, n_views=nv)
+    objs, imgs = P.as_lists()
+    views = O.Views(objs, imgs)
+    g, poses = P.intr_guess(), P.poses_true.numpy()
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    E.set_intr(0, g)
+    E.set_poses(0, poses)
+    E.W.fill_(float("nan"))                      # the no-store form must not touch the block buffers
+    E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
+    assert bool(torch.isnan(E.W).all().item())
+    blk = O.normal_blocks("fisheye", views, g, poses)
+    NI, nu = 8, 36
+    R = E.rec.cpu().numpy()
+    G, S = R[:E.glob_len], R[E.glob_len:]
+    assert rel(sym(G[:nu], NI), blk["U"]) < 1e-11 and rel(G[nu:nu + NI], blk["b"]) < 1e-10
+    assert abs(G[-1] / blk["cost"] - 1) < 1e-12
+    Y = np.linalg.solve(blk["V"], np.concatenate([blk["W"].transpose(0, 2, 1), blk["g"][..., None]], axis=2))
+    C = np.einsum("bik,bkj->ij", blk["W"], Y[..., :-1])
+    d = np.einsum("bik,bk->i", blk["W"], Y[..., -1])
+    assert rel(sym(S[:nu], NI), C) < 1e-10 and rel(S[nu:], d) < 1e-10
+
+
 def test_cost_only_and_per_view_cost(dev, mapping):
     P = synth.config("C3", n_views=300)
     objs, imgs = P.as_lists()
@@ -242,8 +270,10 @@ def _engine_for(P, dev):
     return E
 
 
-def test_full_size_properties_config3_and_5(dev):
-    """Size-independent properties at BASELINE sizes (the oracle cannot run
+@pytest.mark.parametrize("fused", [False, True], ids=["two-pass", "single-pass-no-stores"])
+def test_full_size_properties_config3_and_5(dev, fused):
+    """fused=True is the exact call bench.py times (camcal_normal_eq_fused, no block stores,
+    lambda = 0) at the exact size it times it.  Size-independent properties at BASELINE sizes (the oracle cannot run
     these in seconds): (1) additivity -- the records of the full set equal the
     sum of the records of two halves; (2) view-order invariance; (3) the C
     oracle agrees on a 4000-view sample of the same set; (4) at the true
@@ -252,7 +282,8 @@ def test_full_size_properties_config3_and_5(dev):
         P = synth.config(name, n_views=nv, device=dev)
         E = _engine_for(P, dev)
         E.set_intr(0, P.intr_true())
-        E.normal_eq(0, 0, 0.0)
+        ne = dict(store_blocks=False, fused=True) if fused else {}
+        E.normal_eq(0, 0, 0.0, **ne)
         full = E.rec.cpu().numpy().copy()
         sigma2 = full[E.glob_len - 1] / (2 * P.n_obs)
         assert abs(sigma2 - 0.04) < 0.04 * 0.01 + 1e-5            # noise 0.2 px (+ float32 rounding)
@@ -265,7 +296,7 @@ def test_full_size_properties_config3_and_5(dev):
                               P.poses_true[lo:hi])
             Eh = _engine_for(Q, dev)
             Eh.set_intr(0, P.intr_true())
-            Eh.normal_eq(0, 0, 0.0)
+            Eh.normal_eq(0, 0, 0.0, **ne)
             parts.append(Eh.rec.cpu().numpy().copy())
             del Eh, Q
         assert np.allclose(parts[0] + parts[1], full, rtol=1e-9, atol=1e-6 * np.abs(full).max())
@@ -278,7 +309,7 @@ def test_full_size_properties_config3_and_5(dev):
                           P.obj[:vp[ns]], P.img[:vp[ns]], P.poses_true[:ns])
         Es = _engine_for(Q, dev)
         Es.set_intr(0, P.intr_true())
-        Es.normal_eq(0, 0, 0.0)
+        Es.normal_eq(0, 0, 0.0, **ne)
         G = Es.rec.cpu().numpy()
         nu = 36
         assert rel(sym(G[:nu], 8), r["U"]) < 1e-11 and rel(G[nu:nu + 8], r["b"]) < 1e-9
