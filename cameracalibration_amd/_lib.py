@@ -45,6 +45,7 @@ _SIGNATURES = {
     "camcal_backsub": (C.c_int, [_I, _TP, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
     "camcal_normal_eq": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_normal_eq_fused": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
+    "camcal_normal_eq_fused_static": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P]),
     "camcal_fisheye_gn": (C.c_int, [_TP, _P, _P, C.c_char_p, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "camcal_pinhole_lm": (C.c_int, [_TP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _I, _D, _P,

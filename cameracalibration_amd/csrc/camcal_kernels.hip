@@ -17,6 +17,7 @@
 #include "../../include/camcal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 #include "camcal_lane.h"
 #include "camcal_rig.h"
@@ -1424,6 +1425,36 @@ inline int grid_groups(const camcal_tiles* t, int G) { return (int)((t->n_slots 
 
 }  // namespace
 
+// Scratch of camcal_normal_eq_fused_static: the partial records of one single-pass evaluation,
+// [NR + NS rows][partials] + the reduced values, for callers that cannot allocate.  The name
+// is a host-side stand-in for a per-device array: host code only ever uses the address
+// hipGetSymbolAddress returns for the current device (static_scratch_ptr).
+constexpr int STATIC_MAX_PARTIALS = 16384;        // tiles (one lane per view) or wavefronts (grouped sets)
+constexpr int STATIC_ROWS = 109;                  // pinhole: 55 + 54 (fisheye 37 + 44)
+constexpr size_t STATIC_SCRATCH_DOUBLES = (size_t)STATIC_ROWS * STATIC_MAX_PARTIALS + 2 * MAX_NV;
+static __device__ __align__(256) double static_scratch[STATIC_SCRATCH_DOUBLES];
+
+namespace {
+constexpr int STATIC_MAX_DEVICES = 64;
+std::mutex g_static_mu;
+double* g_static_ptr[STATIC_MAX_DEVICES] = {};
+// device address of `static_scratch` on the current device (looked up once per device)
+int static_scratch_ptr(double** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= STATIC_MAX_DEVICES) return CAMCAL_E_BADARG;
+  std::lock_guard<std::mutex> lk(g_static_mu);
+  if (!g_static_ptr[dev]) {
+    double* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(static_scratch)));
+    if (!p) return CAMCAL_E_BADARG;
+    g_static_ptr[dev] = p;
+  }
+  *out = g_static_ptr[dev];
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int camcal_version(void) { return 100; }
@@ -1734,6 +1765,19 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
   else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
+                                  double lam, double* glob, double* schur, void* stream) {
+  if (!tiles_ok(tiles)) return CAMCAL_E_BADARG;
+  if (camcal_glob_len(model) < 0) return CAMCAL_E_BADMODEL;
+  // partial records of the launch: one per tile, or one per wavefront for a grouped set
+  const int64_t partials = (int64_t)tiles->n_tiles * group_lanes(tiles);
+  if (partials > STATIC_MAX_PARTIALS) return CAMCAL_E_TOOBIG;
+  double* ws = nullptr;
+  const int rc = static_scratch_ptr(&ws);
+  if (rc) return rc;
+  return camcal_normal_eq_fused(model, tiles, intr, pose, lam, nullptr, nullptr, nullptr, glob, schur, ws, stream);
 }
 
 int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles, const double* intr,

@@ -181,6 +181,23 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
                            const double* pose, double lam, double* V, double* W, double* g,
                            double* glob, double* schur, double* scratch, void* stream);
 
+/* The evaluation of camcal_normal_eq_fused (no block stores: V = W = g = NULL) for callers
+ * that cannot allocate device memory or carry a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.
+ * The partial records of the launch go to a file-scope __device__ array inside the library
+ * (109 x 16384 + 192 doubles = 14.3 MB, held by every GPU the library runs on until the
+ * process ends) instead of a caller-provided scratch; the call allocates and frees nothing.
+ * Limit: n_tiles (x 64 or x 16 for the small planar sets that run several lanes per view,
+ * see lanes_per_view) <= 16384 partial records, i.e. up to 1,048,576 views one lane per
+ * view; larger sets return CAMCAL_E_TOOBIG.  glob / schur as in camcal_normal_eq_fused
+ * (schur == glob + camcal_glob_len).  Nothing in the array has to start at zero (a launch
+ * writes every entry it reads), but every call on one GPU shares the array: calls that
+ * overlap on one GPU (two streams, two threads) race.  The first call on a device looks the
+ * array's address up (hipGetSymbolAddress); make it outside stream capture. */
+int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const double* intr,
+                                  const double* pose, double lam, double* glob, double* schur,
+                                  void* stream);
+
 /* ---- Host-side sequencing of whole solves on ONE device (one process): the loops that
  * run inside OpenCV's C++ behind the two reference calls.  They only call the stage entry
  * points above and read a few scalars back per iteration (stream-synchronising); a

@@ -376,6 +376,11 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* t, const double* intr,
   camcal_view_blocks(model, t, intr, pose, V, W, g, s);
   return camcal_schur(model, t, V, W, g, lam, schur_out, scratch, s);
 }
+int camcal_normal_eq_fused_static(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam,
+                                  double* glob, double* schur_out, void* s) {
+  if (t->n_tiles > 16384) return CAMCAL_E_TOOBIG;
+  return camcal_normal_eq_fused(model, t, intr, pose, lam, nullptr, nullptr, nullptr, glob, schur_out, nullptr, s);
+}
 int camcal_time_stage(int, int, int, const camcal_tiles*, const double*, const double*, double, double*, double*,
                       double*, double*, double*, double*, void*, float* ms) { if (ms) *ms = 0.f; return 0; }
 int camcal_solve_reduced(int model, const double* glob, const double* schur, const uint8_t* mask_host, double lam,
