@@ -36,8 +36,39 @@ FLOP_PER_OBS = {"fisheye": 605.0, "pinhole": 732.0}
 FLOP_PER_VIEW = 1200.0
 BYTES_PER_OBS = 20.0      # X Y Z u v float32 (the planar fast path reads 16: Z rows are skipped)
 BYTES_PER_VIEW = 696.0
+# what the timed instantiation (planar, no block stores) moves: X Y u v, the pose, and one partial
+# record [U|b|cost|C|d] of 81 doubles per tile of 64 views written and read once by the second stage
+MOVED_BYTES_PER_OBS = 16.0
+MOVED_BYTES_PER_VIEW = 48.0 + 2.0 * 8.0 * 81.0 / 64.0
 PEAK_FP64_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 FMA lanes x 2 flop x 2.4 GHz (vector FP64)
 PEAK_HBM_GBS = 8000.0
+
+
+def kernel_source_sha():
+    """Hash of the kernel sources: a committed PMC profile only describes the kernels it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("camcal_kernels.hip", "camcal_lane.h", "camcal_math.h"):
+        h.update(open(os.path.join(HERE, "cameracalibration_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(n_obs):
+    """HBM traffic and executed flops of the step's kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, collected by tools/pmc_run.py; PMC cannot be read from inside this
+    process), scaled by observation count.  Values are None when the file is absent and flagged stale
+    when the kernel sources changed since the passes were taken."""
+    out = {"traffic": None, "executed_flop_per_obs": None, "stale": None, "source": None}
+    try:
+        tj = json.load(open(os.path.join(HERE, "profiles", "pmc_traffic.json")))
+        k = tj["k_normal_fused<fisheye,no block stores,planar>"]
+        out["traffic"] = k["hbm_bytes"] * n_obs / tj["workload_obs"]
+        out["executed_flop_per_obs"] = k.get("executed_flop_per_obs")
+        out["stale"] = tj.get("kernel_source_sha") != kernel_source_sha()
+        out["source"] = tj.get("source")
+    except Exception:
+        pass
+    return out
 
 
 def cpu_baseline(seconds_target=12.0):
@@ -247,9 +278,10 @@ def main():
         pass_ms = region_ms if world == 1 else stage_ms["k_normal_fused+finalize (the step)"]
         stage_ms["timed_region_per_step"] = region_ms
         flops = FLOP_PER_OBS["fisheye"] * n_obs + FLOP_PER_VIEW * n_views
-        bytes_alg = BYTES_PER_OBS * n_obs + BYTES_PER_VIEW * n_views
+        bytes_model = BYTES_PER_OBS * n_obs + BYTES_PER_VIEW * n_views
+        bytes_moved = MOVED_BYTES_PER_OBS * n_obs + MOVED_BYTES_PER_VIEW * n_views
         ach_tf = flops / (pass_ms * 1e-3) * 1e-12
-        ach_gb = bytes_alg / (pass_ms * 1e-3) * 1e-9
+        ach_gb = bytes_moved / (pass_ms * 1e-3) * 1e-9
         # measured peaks on this device (BASELINE.md section 3 asks for both)
         import ctypes as C
         res = C.c_double(0.0)
@@ -260,14 +292,10 @@ def main():
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(res))
             probe[key] = float(res.value) if rc == 0 else None
         del buf
-        # HBM traffic of the step's kernel from the committed rocprofv3 PMC passes (scaled by
-        # observation count; null when the profile file is absent)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(HERE, "profiles", "pmc_traffic.json")))
-            traffic = tj["k_normal_fused<fisheye,no block stores,planar>"]["hbm_bytes"] * n_obs / tj["workload_obs"]
-        except Exception:
-            pass
+        pmc = pmc_profile(n_obs)
+        traffic = pmc["traffic"]
+        ex_flop = pmc["executed_flop_per_obs"]
+        ex_tf = (ex_flop * n_obs / (pass_ms * 1e-3) * 1e-12) if ex_flop else None
         out = {
             "metric": "corner-obs/s for residual+Jacobian+Schur (one normal-equation evaluation)",
             "value": world * n_obs * args.steps / el,
@@ -287,11 +315,21 @@ def main():
                               "kernel k_normal_fused (+ its two tiny reduction launches)",
                 "measured_peak_fp64_tflops": probe.get("fp64_fma_tflops"),
                 "frac_of_measured_peak": (ach_tf / probe["fp64_fma_tflops"]) if probe.get("fp64_fma_tflops") else None,
+                # what the FP64 pipe really executes (PMC: FMA x2 + add/mul; less than the model because of the
+                # Hankel / shared-row structure of the fisheye blocks): the busy fraction of the pipe
+                "executed_flop_per_obs": ex_flop, "achieved_executed": ex_tf,
+                "frac_executed": (ex_tf / PEAK_FP64_TFLOPS) if ex_tf else None,
+                "traffic_source": pmc["source"], "traffic_stale": pmc["stale"],
             },
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": ach_gb / PEAK_HBM_GBS, "traffic": traffic,
+                             "frac": ach_gb / PEAK_HBM_GBS, "traffic": traffic, "traffic_stale": pmc["stale"],
+                             "achieved_from_traffic": (traffic / (pass_ms * 1e-3) * 1e-9) if traffic else None,
+                             "bytes_moved": bytes_moved, "bytes_model": bytes_model,
                              "measured_peak_read_gbs": probe.get("hbm_read_gbs"),
-                             "work_model": "20 B/obs + 696 B/view"},
+                             "work_model": "moved by this instantiation (planar, no block stores): 16 B/obs + 48 B/view "
+                                           "pose + one 81-double partial record per 64 views written and re-read; "
+                                           "bytes_model is the frozen 20 B/obs + 696 B/view of SURVEY.md 8d "
+                                           "(3-D points, blocks stored), which this launch does not move"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
