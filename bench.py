@@ -197,6 +197,135 @@ def solve_times(dev, with_cpu=True):
     return out
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator is created; the contract of this
+    script is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def timed_steps(step, steps, world, dev):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; returns (wall seconds, max
+    over ranks; HIP-event milliseconds per step on this rank's stream)."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # the library launches on torch's current stream
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    region_ms = ev0.elapsed_time(ev1) / steps
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), region_ms
+
+
+def make_engine(lib, n_views, dev, seed):
+    """C5 views resident on this rank, in the state of the solver at its first evaluation: poses
+    initialised and refined per view at the guessed intrinsics."""
+    P = synth.config("C5", n_views=n_views, device=dev, seed=seed)
+    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
+    E.set_intr(0, P.intr_guess())
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    n_obs, nv = P.n_obs, P.n_views
+    del P
+    torch.cuda.synchronize()
+    return E, n_obs, nv
+
+
+def make_step(E, lib, handle):
+    import ctypes as C
+    n_rec = E.glob_len + E.schur_len
+
+    def step():
+        E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
+        if handle is not None:         # [U|b|cost|C|d]: one ncclAllReduce on the compute stream
+            with torch.cuda.device(E.device):
+                lib.check(lib.camcal_comm_allreduce(handle, E.rec.data_ptr(), n_rec, E._stream()), "allreduce")
+    return step
+
+
+def kernel_extras(dev, lib):
+    """Bench lines of the other heavy kernels of a solve: the per-view pose
+    re-estimation at C5 size and the pinhole evaluation at the same scale."""
+    out = {}
+    try:
+        P = synth.config("C5", n_views=1_000_000, device=dev)
+        E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
+        E.set_intr(0, P.intr_guess())
+        n_obs = P.n_obs
+        del P
+        E.pose_init(0, 0)
+        start = E.pose[0].clone()
+        ts = []
+        for _ in range(3):
+            E.pose[0].copy_(start)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            E.pose_refine(0, 0, 20, 1e-10)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ms = float(np.median(ts))
+        steps = float(E.iters.double().sum().item()) / 1_000_000
+        flop = 340.0                                   # projection + pose Jacobian + V, g per observation and step
+        tf = flop * n_obs * steps / (ms * 1e-3) * 1e-12
+        out["pose_refine_first"] = {"ms": ms, "mean_gn_steps_per_view": steps, "obs_steps_per_s": n_obs * steps / (ms * 1e-3),
+                                    "flop_per_obs_step_model": flop, "achieved_tflops": tf, "frac_fp64_peak": tf / PEAK_FP64_TFLOPS,
+                                    "note": "k_pose_refine from the homography initialisation, 1M views x 88 corners; views need "
+                                            "2..20 steps each (cv2's rule per view)"}
+        del E, start
+        torch.cuda.empty_cache()
+        P = synth.config("C5P", n_views=1_000_000, device=dev)
+        E = Engine(_lib.PINHOLE, P.view_ptr, P.obj, P.img, dev, lib=lib)
+        E.set_intr(0, P.intr_guess())
+        n_obs, nv = P.n_obs, P.n_views
+        E.pose_init(0, 0)
+        E.pose_refine(0, 0, 20, 1e-10)
+        for st in (0, 5, 4):
+            E.time_stage(st, 20)
+        a, b, f = E.time_stage(0, 100), E.time_stage(5, 100), E.time_stage(4, 100)
+        flops = FLOP_PER_OBS["pinhole"] * n_obs + FLOP_PER_VIEW * nv
+        out["pinhole_evaluation_1M_views"] = {
+            "evaluation_A_ms": a, "evaluation_B_ms": b, "single_pass_ms": f,
+            "obs_per_s_two_pass": n_obs / ((a + b) * 1e-3), "obs_per_s_single_pass": n_obs / (f * 1e-3),
+            "frac_fp64_peak_two_pass": flops / ((a + b) * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS,
+            "frac_fp64_peak_single_pass": flops / (f * 1e-3) * 1e-12 / PEAK_FP64_TFLOPS,
+            "work_model": "732 flop/obs + 1200 flop/view (BASELINE.md section 3); the LM driver uses A + B",
+        }
+        # whole LM solve of the same set (CvLevMarq, criteria of camera_calib.py:153-156)
+        from cameracalibration_amd import solver
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        err, it = solver.lm_pinhole(E, np.ones(9, dtype=bool), 1000, 1e-6)
+        torch.cuda.synchronize()
+        intr = E.get_intr(0)
+        out["C5p_pinhole_1M_views_lm"] = {"ms": (time.perf_counter() - t0) * 1e3, "iterations": it,
+                                         "rms_px": float(np.sqrt(err / n_obs)),
+                                         "fx_rel_err": float(abs(intr[0] / P.K_true[0] - 1)),
+                                         "note": "LM loop only (poses already initialised), points on the device"}
+    except Exception as exc:
+        out["error"] = repr(exc)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,7 +333,13 @@ def main():
     # kernels run up to 17 % slower than the steady state (profiles/README.md, r01_i)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--views", type=int, default=1_000_000, help="views per GPU")
+    ap.add_argument("--views", type=int, default=1_000_000, help="views per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
+                    help="weak: --views per GPU (the headline value); strong: --views in total, sharded; both: "
+                         "the line is the weak run and carries the strong run as 'strong_scaling' (N > 1 only)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="rehearsal of the N > 1 code path on one GPU: a one-rank nccl group, the step includes the "
+                         "library's ncclAllReduce, the strong-scaling run is made too")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solves", action="store_true", help="skip the whole-solve wall-clock extras")
     args = ap.parse_args()
@@ -217,51 +352,49 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    multi = world > 1 or args.force_comm
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = _lib.load()
-    P = synth.config("C5", n_views=args.views, device=dev, seed=5 + rank)
-    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
-    n_obs, n_views = P.n_obs, P.n_views
-    E.set_intr(0, P.intr_guess())
-    # state of the solver at its first evaluation: poses initialised and
-    # refined per view at the guessed intrinsics
-    E.pose_init(0, 0)
-    E.pose_refine(0, 0, 20, 1e-10)
-    del P
-    torch.cuda.synchronize()
-
-    def step():
-        E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
-        if world > 1:
-            dist.all_reduce(E.rec)
-
+    from cameracalibration_amd import solver
+    from cameracalibration_amd.distributed import shard_ranges
+    comm = solver.Comm(enabled=multi)
+    headline = "strong" if (args.scaling == "strong" and multi) else "weak"
+    runs = {}
     # clock ramp: the device needs ~25 launches of this kernel to reach its steady
     # clock, so a short --warmup is topped up to 30 untimed steps in all (reported as "prewarm_steps")
     prewarm = max(0, 30 - args.warmup)
-    for _ in range(prewarm + args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                       # the library launches on torch's current stream
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    region_ms = ev0.elapsed_time(ev1) / args.steps
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    el = float(tmax.item())
+    modes = [headline] + (["strong"] if (args.scaling == "both" and multi) else [])
+    for mode in modes:
+        if mode == "weak":
+            nv_rank = args.views
+        else:                          # BASELINE config 5 as written: --views in total, sharded by observation count
+            lo, hi = shard_ranges(np.full(args.views, 88, dtype=np.int64), world)[rank]
+            nv_rank = hi - lo
+        E, n_obs, n_views = make_engine(lib, nv_rank, dev, seed=5 + rank)
+        with stdout_to_stderr():
+            handle = comm.handle(E)
+        step = make_step(E, lib, handle)
+        for _ in range(prewarm + args.warmup):
+            step()
+        el, region_ms = timed_steps(step, args.steps, world, dev)
+        tot = torch.tensor([float(n_obs)], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tot)
+        runs[mode] = dict(E=E, n_obs=n_obs, n_views=n_views, el=el, region_ms=region_ms, total_obs=float(tot.item()),
+                          comm={"rccl": "library RCCL communicator: one ncclAllReduce of 81 doubles per step on the "
+                                        "compute stream", "torch": "torch.distributed all_reduce (callback)",
+                                None: None}[comm.kind])
+        if mode != headline:
+            del runs[mode]["E"]
+            del E
+            torch.cuda.empty_cache()
+    R = runs[headline]
+    E, n_obs, n_views, el, region_ms = R["E"], R["n_obs"], R["n_views"], R["el"], R["region_ms"]
 
     # per-kernel durations (HIP events on the launch stream), rank 0
     stage_ms = {}
@@ -296,17 +429,19 @@ def main():
         traffic = pmc["traffic"]
         ex_flop = pmc["executed_flop_per_obs"]
         ex_tf = (ex_flop * n_obs / (pass_ms * 1e-3) * 1e-12) if ex_flop else None
+        per = "per GPU" if headline == "weak" else f"in total, sharded over {world} GPUs"
         out = {
             "metric": "corner-obs/s for residual+Jacobian+Schur (one normal-equation evaluation)",
-            "value": world * n_obs * args.steps / el,
+            "value": R["total_obs"] * args.steps / el,
             "unit": "corner-obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm,
             "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": headline, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C5 stress: {n_views} Kannala-Brandt fisheye views x 88 corners per GPU "
-                                   f"({n_obs} corner observations per GPU), 8 intrinsics + 6 per view",
-                       "views_per_gpu": n_views, "obs_per_gpu": n_obs, "parallelism": f"views sharded x{world}"},
+            "config": {"workload": f"C5 stress: {args.views} Kannala-Brandt fisheye views x 88 corners {per} "
+                                   f"({n_obs} corner observations on rank 0), 8 intrinsics + 6 per view",
+                       "views_per_gpu": n_views, "obs_per_gpu": n_obs, "parallelism": f"views sharded x{world}",
+                       "collective": R["comm"]},
             "roofline": {
                 "bound": "fp64-valu", "achieved": ach_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
@@ -331,14 +466,24 @@ def main():
                                            "bytes_model is the frozen 20 B/obs + 696 B/view of SURVEY.md 8d "
                                            "(3-D points, blocks stored), which this launch does not move"},
         }
+        if "strong" in runs and headline != "strong":
+            S = runs["strong"]
+            out["strong_scaling"] = {"value": S["total_obs"] * args.steps / S["el"], "unit": "corner-obs/s",
+                                     "ms_per_step": S["el"] / args.steps * 1e3, "views_total": args.views,
+                                     "views_on_rank0": S["n_views"], "kernel_region_ms_rank0": S["region_ms"],
+                                     "note": "BASELINE config 5 as written: the 1M-view set sharded over the ranks "
+                                             "(shard_ranges), same step, same collective"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_solves:
-            del E
+            del E, R, runs
             torch.cuda.empty_cache()
             out["solve_wall_clock"] = solve_times(dev, with_cpu=not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
+            out["kernels"] = kernel_extras(dev, lib)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
+        solver.destroy_rccl_comms()
         dist.destroy_process_group()
 
 

@@ -26,6 +26,15 @@ class Tiles(C.Structure):
 _P, _I, _D = C.c_void_p, C.c_int, C.c_double
 _TP = C.POINTER(Tiles)
 
+# int (*allreduce_sum)(void* ctx, double* buf, int64_t n, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class CommStruct(C.Structure):
+    """struct camcal_comm (include/camcal.h)."""
+    _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("ctx", C.c_void_p)]
+
+
 _SIGNATURES = {
     "camcal_version": (C.c_int, []),
     "camcal_set_lanes_per_view": (C.c_int, [C.c_int]),
@@ -46,9 +55,13 @@ _SIGNATURES = {
     "camcal_normal_eq": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_normal_eq_fused": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_normal_eq_fused_static": (C.c_int, [_I, _TP, _P, _P, _D, _P, _P, _P]),
-    "camcal_fisheye_gn": (C.c_int, [_TP, _P, _P, C.c_char_p, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P,
+    "camcal_rccl_unique_id": (C.c_int, [_P]),
+    "camcal_comm_rccl_create": (C.c_int, [_P, _I, _I, C.POINTER(_P)]),
+    "camcal_comm_destroy": (C.c_int, [_P]),
+    "camcal_comm_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "camcal_fisheye_gn": (C.c_int, [_TP, _P, _P, C.c_char_p, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
-    "camcal_pinhole_lm": (C.c_int, [_TP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _I, _D, _P,
+    "camcal_pinhole_lm": (C.c_int, [_TP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _I, _D, _P, _P,
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_float)]),
@@ -69,8 +82,15 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+E_NUMERIC, E_COMM = -4, -5
+
+
 class CamcalError(RuntimeError):
     pass
+
+
+class CamcalNumericError(CamcalError):
+    """CAMCAL_E_NUMERIC: a solver loop met a singular system or a non-finite cost."""
 
 
 class CamcalLib:
@@ -90,6 +110,8 @@ class CamcalLib:
         self.is_emulator = self.camcal_version() < 0
 
     def check(self, rc: int, what: str):
+        if rc == E_NUMERIC:
+            raise CamcalNumericError(f"{what}: singular system or non-finite cost (degenerate views?)")
         if rc != 0:
             raise CamcalError(f"{what} failed with status {rc}"
                               + (" (hipError_t)" if rc > 0 else " (CAMCAL_E_*)"))

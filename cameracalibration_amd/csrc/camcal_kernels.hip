@@ -17,6 +17,7 @@
 #include "../../include/camcal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 #include "camcal_lane.h"
@@ -2034,6 +2035,89 @@ int camcal_peak_probe(int kind, void* buf, int64_t bytes, int reps, void* stream
   return 0;
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Communicator (include/camcal.h): RCCL opened at run time, one ncclAllReduce per record on
+// the caller's stream.  The prototypes are RCCL's (rccl.h: ncclGetUniqueId, ncclCommInitRank,
+// ncclAllReduce, ncclCommDestroy; ncclDouble = 8, ncclSum = 0, ncclSuccess = 0).
+#include <dlfcn.h>
+namespace {
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+  int (*get_unique_id)(RcclUniqueId*) = nullptr;
+  int (*comm_init_rank)(void** comm, int nranks, RcclUniqueId id, int rank) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int, int, void* comm, hipStream_t) = nullptr;
+  int (*comm_destroy)(void* comm) = nullptr;
+  bool ok = false;
+};
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+const RcclApi* rccl_api() {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!g_rccl.ok) {
+    // by soname: a process that already holds an RCCL (PyTorch's) gets that one
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return nullptr;
+    g_rccl.get_unique_id = (decltype(g_rccl.get_unique_id))dlsym(h, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(h, "ncclCommInitRank");
+    g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(h, "ncclAllReduce");
+    g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.all_reduce && g_rccl.comm_destroy;
+  }
+  return g_rccl.ok ? &g_rccl : nullptr;
+}
+struct RcclComm {
+  camcal_comm base;        // first member: the handle handed out
+  void* nccl = nullptr;
+};
+int rccl_allreduce_sum(void* ctx, double* buf, int64_t n, void* stream) {
+  const RcclComm* c = (const RcclComm*)ctx;
+  const RcclApi* api = rccl_api();
+  if (!c || !c->nccl || !api) return CAMCAL_E_COMM;
+  return api->all_reduce(buf, buf, (size_t)n, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->nccl, (hipStream_t)stream) == 0
+             ? 0 : CAMCAL_E_COMM;
+}
+}  // namespace
+
+extern "C" {
+int camcal_rccl_unique_id(void* id128_host) {
+  if (!id128_host) return CAMCAL_E_BADARG;
+  const RcclApi* api = rccl_api();
+  if (!api) return CAMCAL_E_COMM;
+  return api->get_unique_id((RcclUniqueId*)id128_host) == 0 ? 0 : CAMCAL_E_COMM;
+}
+int camcal_comm_rccl_create(const void* id128_host, int rank, int world_size, camcal_comm** comm_out) {
+  if (!id128_host || !comm_out || world_size < 1 || rank < 0 || rank >= world_size) return CAMCAL_E_BADARG;
+  const RcclApi* api = rccl_api();
+  if (!api) return CAMCAL_E_COMM;
+  RcclUniqueId id;
+  std::memcpy(&id, id128_host, sizeof(id));
+  RcclComm* c = new RcclComm();
+  if (api->comm_init_rank(&c->nccl, world_size, id, rank) != 0 || !c->nccl) {
+    delete c;
+    return CAMCAL_E_COMM;
+  }
+  c->base.allreduce_sum = rccl_allreduce_sum;
+  c->base.ctx = c;
+  *comm_out = &c->base;
+  return 0;
+}
+int camcal_comm_destroy(camcal_comm* comm) {
+  if (!comm) return 0;
+  if (comm->allreduce_sum != rccl_allreduce_sum) return CAMCAL_E_BADARG;   // not one of ours
+  RcclComm* c = (RcclComm*)comm->ctx;
+  const RcclApi* api = rccl_api();
+  if (api && c->nccl) api->comm_destroy(c->nccl);
+  delete c;
+  return 0;
+}
+int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void* stream) {
+  if (!comm) return 0;
+  if (!comm->allreduce_sum || !buf || n <= 0) return CAMCAL_E_BADARG;
+  return comm->allreduce_sum(comm->ctx, buf, n, stream);
+}
 }  // extern "C"
 
 // ---------------------------------------------------------------------------

@@ -106,8 +106,8 @@ class Engine:
         # solver buffers: one zeroed allocation, carved up (every piece a multiple of 8 bytes)
         NI = self.NI
         sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
-                     W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, dK=16, stats=8,
-                     norms=2, view_cost=S)
+                     W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, norms=2, dK=16,
+                     stats=8, view_cost=S)        # norms right behind glob1: one all-reduce for a trial point
         pool = torch.zeros(sum(sizes.values()), **f64)
         part, off = {}, 0
         for k, n_k in sizes.items():
@@ -260,18 +260,19 @@ class Engine:
     def _mask_bytes(mask):
         return bytes(bytearray(int(bool(x)) for x in mask))
 
-    def solve_fisheye(self, mask, criteria, recompute_extrinsic=True):
+    def solve_fisheye(self, mask, criteria, recompute_extrinsic=True, comm=None):
         """cv::fisheye::calibrate's loop from ``intr[0]`` / ``pose[0]`` (camcal_fisheye_gn).
-        Returns (sum of squared residuals, iterations)."""
+        ``comm``: pointer to a camcal_comm (multi-rank solve) or None.
+        Returns (sum of squared residuals over all ranks, iterations)."""
         ctype, maxc, eps = criteria
         cost, its = C.c_double(0.0), C.c_int32(0)
         self._call("camcal_fisheye_gn", self._tp(), self.intr[0].data_ptr(), self.pose[0].data_ptr(),
                    self._mask_bytes(mask), int(ctype), int(maxc), float(eps), 1 if recompute_extrinsic else 0,
                    self.rec.data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(), self.iters.data_ptr(),
-                   self.scratch.data_ptr(), self._stream(), C.byref(cost), C.byref(its))
+                   self.scratch.data_ptr(), comm, self._stream(), C.byref(cost), C.byref(its))
         return float(cost.value), int(its.value)
 
-    def solve_pinhole(self, mask, max_iter, eps):
+    def solve_pinhole(self, mask, max_iter, eps, comm=None):
         """CvLevMarq loop from ``intr[0]`` / ``pose[0]`` (camcal_pinhole_lm); on return
         buffer 0 holds the result.  Returns (errNorm2, iterations)."""
         two = C.c_void_p * 2
@@ -283,7 +284,7 @@ class Engine:
                    two(self.gs[0].data_ptr(), self.gs[1].data_ptr()),
                    self.W.data_ptr(), self.rec.data_ptr(), self.glob[1].data_ptr(), self.dK.data_ptr(),
                    self.stats.data_ptr(), self.norms.data_ptr(), self.scratch.data_ptr(), self._mask_bytes(mask),
-                   int(max_iter), float(eps), self._stream(), C.byref(err), C.byref(its), C.byref(cur))
+                   int(max_iter), float(eps), comm, self._stream(), C.byref(err), C.byref(its), C.byref(cur))
         if cur.value == 1:                   # the result sits in the second buffers: make them buffer 0
             self.intr.reverse()
             self.pose.reverse()

@@ -8,30 +8,57 @@ iteration (cost, step norms) to take the accept / reject / stop decisions that
 [OpenCV 4.10 compat_ptsetreg.cpp, fisheye.cpp; SURVEY.md 8(c)-appendix].
 
 Multi-GPU: views are sharded across ranks (one process per GPU).  The only
-exchanged data are the small global records -- ``[U|b|cost]``, ``[C|d]`` and the
-step norms -- summed with one ``torch.distributed.all_reduce`` each (RCCL on
-GPUs, gloo in the CPU tests).  Every rank then solves the reduced system
-redundantly and back-substitutes its own poses.
+exchanged data are the small global records -- ``[U|b|cost|C|d]`` per fisheye
+iteration; ``[C|d]`` and ``[U|b|cost|step norms]`` per pinhole trial step --
+summed inside the library's loops through a ``camcal_comm`` (its own RCCL
+communicator on GPUs, a torch.distributed callback over gloo in the CPU tests).
+Every rank then solves the reduced system redundantly and back-substitutes its
+own poses.  The loops below are the logging path (``_info={"log": True}``).
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 DBL_EPSILON = float(np.finfo(np.float64).eps)
 
 
-class Comm:
-    """Sum-all-reduce of small device records; identity for a single rank."""
+# library RCCL communicators, one per (process group, device): creating one costs a
+# rendezvous, so repeated drop-in calls share it; they live until the process ends
+_RCCL_COMMS = {}
 
-    def __init__(self, group=None, enabled=None):
+
+class Comm:
+    """Sum-all-reduce of the small global records; identity for a single rank.
+
+    The solver loops run inside the library (camcal_fisheye_gn / camcal_pinhole_lm) and
+    call the communicator between their stages through a ``camcal_comm`` handle
+    (include/camcal.h), made by :meth:`handle`:
+
+    * ``backend="rccl"`` (default on ROCm devices with the nccl process group): the library's
+      own RCCL communicator -- one ``ncclAllReduce`` on the compute stream per record, no
+      Python and no host synchronisation inside an iteration.  Its unique id travels from
+      rank 0 through ``torch.distributed``.
+    * ``backend="torch"`` (gloo in the CPU tests; ``CAMCAL_COMM=torch`` forces it): a callback
+      that runs ``torch.distributed.all_reduce`` on the engine's own tensor.
+
+    The Python loops of this module (iteration log) use :meth:`allreduce` directly."""
+
+    def __init__(self, group=None, enabled=None, backend=None):
         if enabled is None:
             enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.enabled = bool(enabled)
         self.group = group
+        self.backend = backend or os.environ.get("CAMCAL_COMM") or None
+        self._keep = []            # ctypes callbacks / structs that must outlive the calls
+        self.kind = None           # what the last handle() returned: "rccl" | "torch" | None
 
     def allreduce(self, t: torch.Tensor):
         if self.enabled:
@@ -44,6 +71,90 @@ class Comm:
         t = torch.tensor([float(x)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
+
+    # -- camcal_comm handles --------------------------------------------------------------
+    def _rccl_handle(self, lib, device):
+        key = (id(self.group) if self.group is not None else None,
+               device.index if device.index is not None else torch.cuda.current_device())
+        if key in _RCCL_COMMS:
+            return _RCCL_COMMS[key][1]
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        ident = torch.zeros(128, dtype=torch.uint8)
+        ok = torch.ones(1, dtype=torch.int32)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            if lib.camcal_rccl_unique_id(C.addressof(buf)) != 0:
+                ok[0] = 0
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        on_dev = dist.get_backend(self.group) == "nccl"
+        pack = torch.cat([ok.view(torch.uint8), ident])
+        pack = pack.to(device) if on_dev else pack
+        dist.broadcast(pack, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        pack = pack.cpu()
+        if int(pack[:4].view(torch.int32).item()) == 0:
+            return None
+        idb = bytes(pack[4:].numpy().tobytes())
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = lib.camcal_comm_rccl_create(idb, rank, world, C.byref(out))
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device if on_dev else "cpu")
+        dist.all_reduce(good, op=dist.ReduceOp.MIN, group=self.group)     # all ranks or none
+        if int(good.item()) == 0:
+            if rc == 0:
+                lib.camcal_comm_destroy(out)
+            return None
+        _RCCL_COMMS[key] = (lib, out)
+        return out
+
+    def _torch_handle(self, E):
+        """Callback communicator: the buffers the loops reduce are slices of the engine's pool."""
+        pool = E._pool
+        base, nbytes = pool.data_ptr(), pool.numel() * 8
+        group = self.group
+
+        def cb(ctx, buf, n, stream):
+            try:
+                off = int(buf) - base
+                if off < 0 or off % 8 or off + 8 * n > nbytes:
+                    return -1
+                dist.all_reduce(pool[off // 8: off // 8 + n], op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:          # never unwind through the C frames
+                return -5
+        fn = _lib.ALLREDUCE_FN(cb)
+        st = _lib.CommStruct(fn, None)
+        self._keep.append((fn, st, pool))
+        return C.pointer(st)
+
+    def handle(self, E):
+        """``camcal_comm*`` for the library's loops on engine ``E`` (None for one rank)."""
+        self.kind = None
+        if not self.enabled:
+            return None
+        want = self.backend
+        if want is None:
+            want = "rccl" if (E.device.type == "cuda" and not E.lib.is_emulator
+                              and dist.get_backend(self.group) == "nccl") else "torch"
+        if want == "rccl":
+            h = self._rccl_handle(E.lib, E.device)
+            if h is not None:
+                self.kind = "rccl"
+                return h
+            import warnings
+            warnings.warn("camcal: RCCL communicator unavailable, using torch.distributed for the records")
+        self.kind = "torch"
+        return self._torch_handle(E)
+
+    def close(self):
+        """Drop the callback handles of this object (library RCCL communicators are shared
+        and stay; :func:`destroy_rccl_comms` ends them -- collectively, on every rank)."""
+        self._keep.clear()
+
+
+def destroy_rccl_comms():
+    for lib, h in _RCCL_COMMS.values():
+        lib.camcal_comm_destroy(h)
+    _RCCL_COMMS.clear()
 
 
 def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
@@ -59,8 +170,8 @@ def lm_pinhole(E, mask, max_iter, eps, comm=None, log=None):
     comm = comm or Comm(enabled=False)
     max_iter = int(min(max(max_iter, 1), 1000))
     eps = max(float(eps), DBL_EPSILON)
-    if not comm.enabled and log is None:
-        return E.solve_pinhole(mask, max_iter, eps)       # same loop, sequenced by the library
+    if log is None:
+        return E.solve_pinhole(mask, max_iter, eps, comm=comm.handle(E))   # same loop, sequenced by the library
     lam_lg10 = -3
     cur, tri = 0, 1
     cost_idx = E.glob_len - 1
@@ -112,8 +223,8 @@ def gn_fisheye(E, mask, criteria, recompute_extrinsic=True, comm=None, log=None)
     (CalibrateExtrinsics).  Returns (cost, iterations)."""
     comm = comm or Comm(enabled=False)
     ctype, maxc, eps = criteria
-    if not comm.enabled and log is None:
-        return E.solve_fisheye(mask, (ctype, maxc, eps), recompute_extrinsic)   # same loop, in the library
+    if log is None:
+        return E.solve_fisheye(mask, (ctype, maxc, eps), recompute_extrinsic, comm=comm.handle(E))   # same loop, in the library
     change, it = 1.0, 0
     cost_idx = E.glob_len - 1
     while True:

@@ -45,6 +45,8 @@ extern "C" {
 #define CAMCAL_E_BADARG  (-1)
 #define CAMCAL_E_BADMODEL (-2)
 #define CAMCAL_E_TOOBIG  (-3)
+#define CAMCAL_E_NUMERIC (-4)   /* a solve met a singular system or a non-finite cost (degenerate views) */
+#define CAMCAL_E_COMM    (-5)   /* RCCL missing or a collective failed */
 
 /* Packed observations of the views owned by this process (device pointers). */
 typedef struct camcal_tiles {
@@ -198,10 +200,39 @@ int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const do
                                   const double* pose, double lam, double* glob, double* schur,
                                   void* stream);
 
-/* ---- Host-side sequencing of whole solves on ONE device (one process): the loops that
- * run inside OpenCV's C++ behind the two reference calls.  They only call the stage entry
- * points above and read a few scalars back per iteration (stream-synchronising); a
- * multi-rank solve needs an all-reduce between the stages and is sequenced by the caller.
+/* ---- Multi-GPU: views shard across ranks (one process per GPU); the only data exchanged are
+ * the small global records, summed over the ranks between the stages of a solve.  The
+ * reference has no counterpart (single process).  A camcal_comm tells the solver loops how
+ * to sum: allreduce_sum(ctx, buf, n, stream) adds the n doubles at buf (device memory) over
+ * all ranks in place, ordered on `stream` (it must not block the host on other ranks'
+ * progress beyond what the collective itself needs), and returns 0 on success. */
+typedef struct camcal_comm {
+  int (*allreduce_sum)(void* ctx, double* buf, int64_t n, void* stream);
+  void* ctx;
+} camcal_comm;
+
+/* RCCL-backed communicator, created by the library itself (librccl.so.1 is opened on first
+ * use; a single-GPU process never loads it): rank 0 obtains 128 bytes with
+ * camcal_rccl_unique_id and hands them to every rank by any out-of-band means
+ * (torch.distributed broadcast, MPI, a file); every rank then calls camcal_comm_rccl_create
+ * with its device current.  allreduce_sum of such a communicator is ONE ncclAllReduce
+ * (ncclDouble, ncclSum, in place) enqueued on the caller's stream: no host synchronisation,
+ * no staging copy. */
+int camcal_rccl_unique_id(void* id128_host);
+int camcal_comm_rccl_create(const void* id128_host, int rank, int world_size, camcal_comm** comm_out);
+int camcal_comm_destroy(camcal_comm* comm);
+/* comm->allreduce_sum(...) for hosts without function-pointer calls (ctypes); comm == NULL is
+ * the identity (one rank) */
+int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void* stream);
+
+/* ---- Host-side sequencing of whole solves: the loops that run inside OpenCV's C++ behind
+ * the two reference calls.  They only call the stage entry points above and read a few
+ * scalars back per iteration (waiting on an event, not on the stream).  comm == NULL: one
+ * rank.  With a communicator every rank calls the loop with its own shard of the views and
+ * the same starting intrinsics; the records are summed over the ranks inside the loop
+ * (fisheye: one all-reduce of [U|b|cost|C|d] per iteration; pinhole: [C|d] before the
+ * reduced solve and [U|b|cost | step norms] of the trial point after it), every rank solves
+ * the reduced system redundantly and keeps its own poses.
  * _host pointers are host memory, everything else is device memory. */
 
 /* cv::fisheye::calibrate's loop (camera_calib.py:74-77): until the criteria stop it
@@ -213,21 +244,24 @@ int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const do
  * cost_out_host = sum of squared residuals at the result. */
 int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
                       int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec,
-                      double* dK, double* stats, int32_t* iters, double* scratch, void* stream,
-                      double* cost_out_host, int32_t* iterations_out_host);
+                      double* dK, double* stats, int32_t* iters, double* scratch, const camcal_comm* comm,
+                      void* stream, double* cost_out_host, int32_t* iterations_out_host);
 
 /* CvLevMarq::updateAlt as cvCalibrateCamera2Internal drives it (camera_calib.py:153-156) on
  * the eliminated system: lambda starts at 1e-3, x10 on a rejected step (only the stored-
  * block Schur kernel is repeated), /10 on an accepted one; stops after max_iter accepted
  * steps or when the relative parameter change < eps.  intr2 / pose2 / V2 / g2: the two
  * buffers of each double-buffered quantity (HOST arrays of two device pointers; [0] holds
- * the starting point), W NI*6*n_slots, rec as above, glob_trial camcal_glob_len, norms 2.
- * current_out_host = index (0 / 1) of the buffers that hold the result. */
+ * the starting point), W NI*6*n_slots, rec as above, glob_trial camcal_glob_len, norms 2
+ * (with a communicator, norms == glob_trial + camcal_glob_len makes the trial's records one
+ * all-reduce instead of two).  current_out_host = index (0 / 1) of the buffers that hold the
+ * result. */
 int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double* const pose2[2],
                       double* const V2[2], double* const g2[2], double* W, double* rec,
                       double* glob_trial, double* dK, double* stats, double* norms, double* scratch,
-                      const uint8_t* mask_host, int max_iter, double eps, void* stream,
-                      double* err_out_host, int32_t* iterations_out_host, int32_t* current_out_host);
+                      const uint8_t* mask_host, int max_iter, double eps, const camcal_comm* comm,
+                      void* stream, double* err_out_host, int32_t* iterations_out_host,
+                      int32_t* current_out_host);
 
 /* Timing helper for benchmarks: average duration in milliseconds of `reps`
  * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,

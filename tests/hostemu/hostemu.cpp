@@ -533,6 +533,15 @@ int camcal_remap_u8(const unsigned char* src, int sw, int sh, int64_t sstride, i
     }
   return 0;
 }
+// the emulator has no RCCL; a caller-provided communicator (the tests' gloo callback) works as in the HIP library
+int camcal_rccl_unique_id(void*) { return CAMCAL_E_COMM; }
+int camcal_comm_rccl_create(const void*, int, int, camcal_comm**) { return CAMCAL_E_COMM; }
+int camcal_comm_destroy(camcal_comm* c) { return c ? CAMCAL_E_BADARG : 0; }
+int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void* stream) {
+  if (!comm) return 0;
+  if (!comm->allreduce_sum || !buf || n <= 0) return CAMCAL_E_BADARG;
+  return comm->allreduce_sum(comm->ctx, buf, n, stream);
+}
 int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 0.0; return 0; }
 }  // extern "C"
 

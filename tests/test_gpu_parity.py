@@ -333,3 +333,42 @@ def test_large_solve_recovers_truth(dev):
     want = 0.2 * np.sqrt((2 * P.n_obs - 6 * P.n_views - 8) / P.n_obs)
     assert abs(rms - want) < 1e-3
     assert np.allclose(intr[:4], P.K_true, rtol=1e-4) and np.allclose(intr[4:], P.D_true, atol=2e-4)
+
+
+def test_multi_rank_loop_through_the_library_communicators(dev):
+    """The in-library loops with a communicator (camcal_fisheye_gn / camcal_pinhole_lm, comm != NULL) on the
+    GPU: a one-rank nccl process group gives (a) the library's own RCCL communicator (ncclAllReduce on the
+    compute stream) and (b) the torch.distributed callback; with one rank both sums are the identity, so the
+    results must equal the plain single-rank solve bit for bit.  (More ranks than one need more GPUs than
+    this tier has; the N > 1 arithmetic is covered by the gloo world-2 tests.)"""
+    import torch.distributed as dist
+    from cameracalibration_amd.solver import Comm
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for cfg, nv in (("C2", 300), ("C1", 20)):
+            P = synth.config(cfg, n_views=nv)
+            objs, imgs = P.as_lists()
+            fn, fl = (cc.calibrateCamera, 1) if P.model == "pinhole" else (cc.fisheye.calibrate, FE)
+            ref = fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT)
+            for backend in ("rccl", "torch"):
+                comm = Comm(enabled=True, backend=backend)
+                r = fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT, _comm=comm)
+                assert comm.kind == backend
+                assert r[0] == ref[0] and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
+                assert np.array_equal(np.hstack(r[3]), np.hstack(ref[3]))
+        # the collective itself: in place, on the stream, value-preserving for one rank
+        lib = _lib.load()
+        E = Engine(1, P.view_ptr, P.obj, P.img, dev) if P.model == "fisheye" else Engine(0, P.view_ptr, P.obj, P.img, dev)
+        comm = Comm(enabled=True, backend="rccl")
+        h = comm.handle(E)
+        E.rec.copy_(torch.arange(E.rec.numel(), dtype=torch.float64, device=dev))
+        lib.check(lib.camcal_comm_allreduce(h, E.rec.data_ptr(), E.rec.numel(), E._stream()), "allreduce")
+        assert torch.equal(E.rec.cpu(), torch.arange(E.rec.numel(), dtype=torch.float64))
+    finally:
+        from cameracalibration_amd import solver
+        solver.destroy_rccl_comms()
+        dist.destroy_process_group()
