@@ -25,8 +25,13 @@ examples: examples/cabi_fisheye
 examples/cabi_fisheye: examples/cabi_fisheye.cpp include/camcal.h $(CSRC)/libcamcal.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 $< -o $@ -L$(CSRC) -lcamcal -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
 
+# issue-rate microbenchmarks behind DESIGN.md section 4 (run on the GPU box: tools/ubench/ubench)
+ubench: tools/ubench/ubench
+tools/ubench/ubench: tools/ubench/ubench.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
 clean:
-	rm -f $(CSRC)/libcamcal.so tests/hostemu/libcamcal_hostemu.so examples/cabi_fisheye
+	rm -f tools/ubench/ubench $(CSRC)/libcamcal.so tests/hostemu/libcamcal_hostemu.so examples/cabi_fisheye
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib hostemu oracle examples clean
+.PHONY: all lib hostemu oracle examples ubench clean

@@ -20,7 +20,7 @@ class Tiles(C.Structure):
     """struct camcal_tiles (include/camcal.h)."""
     _fields_ = [("pts", C.c_void_p), ("tile_off", C.c_void_p), ("tile_nmax", C.c_void_p),
                 ("lane_n", C.c_void_p), ("n_tiles", C.c_int32), ("n_slots", C.c_int64),
-                ("planar", C.c_int32)]
+                ("planar", C.c_int32), ("lanes_per_view", C.c_int32)]
 
 
 _P, _I, _D = C.c_void_p, C.c_int, C.c_double
@@ -37,7 +37,6 @@ class CommStruct(C.Structure):
 
 _SIGNATURES = {
     "camcal_version": (C.c_int, []),
-    "camcal_set_lanes_per_view": (C.c_int, [C.c_int]),
     "camcal_n_intr": (C.c_int, [_I]),
     "camcal_glob_len": (C.c_int, [_I]),
     "camcal_schur_len": (C.c_int, [_I]),

@@ -175,6 +175,19 @@ def _poses_to_tuples(poses):
     return rvecs, tvecs
 
 
+def _raise_degenerate(E, cause=None):
+    """cv2 has no usable answer for a view whose points are collinear or coincident (its
+    homography / SVD pose start is garbage and the solve returns non-finite values for the
+    caller's checkRange); this module raises instead and names the views."""
+    st = E.slots_to_views(E.status)
+    bad = np.flatnonzero(st != 0)
+    if bad.size:
+        raise error("degenerate view(s) %s: the pose initialisation failed (collinear / coincident points); "
+                    "remove them" % (bad[:16].tolist(),))
+    if cause is not None:
+        raise error("the solve met a singular system or a non-finite cost (%s)" % cause)
+
+
 def _pinhole_mask(flags, nd):
     mask = np.ones(9, dtype=bool)
     if flags & CALIB_FIX_FOCAL_LENGTH:
@@ -187,7 +200,7 @@ def _pinhole_mask(flags, nd):
         mask[4] = False
     if flags & CALIB_FIX_K2:
         mask[5] = False
-    if flags & CALIB_FIX_K3 or nd < 5:
+    if flags & CALIB_FIX_K3:
         mask[8] = False
     return mask
 
@@ -253,13 +266,23 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     E.pose_refine(0, 0, 20, 1e-10)
     comm = _comm or _solver.Comm()
     log = [] if (_info is not None and _info.get("log") is True) else None
-    err, iters = _solver.lm_pinhole(E, mask, maxc, eps, comm=comm, log=log)
+    try:
+        err, iters = _solver.lm_pinhole(E, mask, maxc, eps, comm=comm, log=log)
+    except _lib.CamcalNumericError as exc:
+        _raise_degenerate(E, exc)
+        raise
+    _raise_degenerate(E)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(err / n_total))
     intr = E.get_intr(0)
     poses = E.get_poses(0)
     Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])
-    Dout = intr[4:4 + D.size].reshape(np.asarray(distCoeffs).shape)
+    if D.size == 5:
+        Dout = intr[4:9].reshape(np.asarray(distCoeffs).shape)
+    else:
+        # cv2 pads a 4-coefficient guess to its 5-coefficient model (prepareDistCoeffs + rowRange(0, 5)),
+        # estimates k3 unless CALIB_FIX_K3 and hands back a NEW 5-element array in the input's orientation
+        Dout = intr[4:9].reshape((1, 5) if (D.ndim == 2 and D.shape[0] == 1) else (5, 1))
     if _info is not None:
         _info.update(iters=iters, log=log, engine=E)
     rv, tv = _poses_to_tuples(poses)
@@ -313,9 +336,14 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
     E.pose_refine(0, 0, 20, 1e-10)
     comm = _comm or _solver.Comm()
     log = [] if (_info is not None and _info.get("log") is True) else None
-    cost, iters = _solver.gn_fisheye(E, mask, tuple(criteria),
-                                     recompute_extrinsic=bool(flags & FISHEYE_CALIB_RECOMPUTE_EXTRINSIC),
-                                     comm=comm, log=log)
+    try:
+        cost, iters = _solver.gn_fisheye(E, mask, tuple(criteria),
+                                         recompute_extrinsic=bool(flags & FISHEYE_CALIB_RECOMPUTE_EXTRINSIC),
+                                         comm=comm, log=log)
+    except _lib.CamcalNumericError as exc:
+        _raise_degenerate(E, exc)
+        raise
+    _raise_degenerate(E)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(cost / n_total))
     intr = E.get_intr(0)

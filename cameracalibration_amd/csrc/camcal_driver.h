@@ -7,12 +7,14 @@
 // host round trip of their own.
 //
 // Included by camcal_kernels.hip and by the tests' CPU lane emulator; the
-// includer provides
-//   int camcal_read_begin(const double* src, int n, int offset, void* stream)
-//   int camcal_read_end(double* dst_host, int n_total)
+// includer provides, with internal linkage,
+//   struct camcal_reader {            // one per running solve (RAII)
+//     int begin(const double* src, int n, int offset, void* stream);
+//     int end(double* dst_host, int n_total);
+//   };
 //   int camcal_copy_doubles(double* dst, const double* src, int n, void* stream)
-// (read_begin: asynchronous copy of n doubles to position `offset` of a per-thread landing
-// buffer, ordered on the stream; read_end: wait for the LAST begin and hand out the first
+// (begin: asynchronous copy of n doubles to position `offset` of the reader's landing
+// buffer, ordered on the stream; end: wait for the LAST begin and hand out the first
 // n_total doubles -- work enqueued after the begin keeps running meanwhile;
 // copy_doubles: device -> device on the stream).
 #pragma once
@@ -20,10 +22,6 @@
 #include <cstdint>
 
 #include "../../include/camcal.h"
-
-int camcal_read_begin(const double* src, int n, int offset, void* stream);
-int camcal_read_end(double* dst_host, int n_total);
-int camcal_copy_doubles(double* dst, const double* src, int n, void* stream);
 
 #define CAMCAL_DRV_TRY(x)      \
   do {                         \
@@ -41,6 +39,7 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
       !iterations_out_host || crit_type < 1 || crit_type > 3)
     return CAMCAL_E_BADARG;
   const int ng = camcal_glob_len(CAMCAL_FISHEYE), ns = camcal_schur_len(CAMCAL_FISHEYE);
+  camcal_reader rd;
   double change = 1.0;
   int it = 0;
   for (;;) {
@@ -54,10 +53,10 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
     CAMCAL_DRV_TRY(camcal_solve_reduced(CAMCAL_FISHEYE, rec, rec + ng, mask_host, 0.0, -alpha2, intr, intr, dK,
                                         stats, stream));
     double st[5];
-    CAMCAL_DRV_TRY(camcal_read_begin(stats, 5, 0, stream));
+    CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
     // cv2 re-estimates the poses before it looks at `change`: the launch does not wait for the host
     if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
-    CAMCAL_DRV_TRY(camcal_read_end(st, 5));
+    CAMCAL_DRV_TRY(rd.end(st, 5));
     // a view whose 6x6 block is not positive definite poisons C, d with NaN; a singular reduced
     // system leaves no step (cv2 would throw from its solve / produce NaN for the caller's checkRange)
     if (st[4] == 0.0 || !std::isfinite(st[2]) || !std::isfinite(st[3])) return CAMCAL_E_NUMERIC;
@@ -67,8 +66,8 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
   CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
                                     stream));
   CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rec + ng - 1, 1, stream));
-  CAMCAL_DRV_TRY(camcal_read_begin(rec + ng - 1, 1, 0, stream));
-  CAMCAL_DRV_TRY(camcal_read_end(cost_out_host, 1));
+  CAMCAL_DRV_TRY(rd.begin(rec + ng - 1, 1, 0, stream));
+  CAMCAL_DRV_TRY(rd.end(cost_out_host, 1));
   *iterations_out_host = it;
   return std::isfinite(*cost_out_host) ? 0 : CAMCAL_E_NUMERIC;
 }
@@ -85,6 +84,7 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
     if (!intr2[k] || !pose2[k] || !V2[k] || !g2[k]) return CAMCAL_E_BADARG;
   const int M = CAMCAL_PINHOLE;
   const int ng = camcal_glob_len(M), ns = camcal_schur_len(M);
+  camcal_reader rd;
   double* glob = rec;                  // [U|b|cost] of the current point
   double* schur = rec + ng;            // [C|d]
   max_iter = max_iter < 1 ? 1 : (max_iter > 1000 ? 1000 : max_iter);
@@ -95,8 +95,8 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
                                     stream));
   CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob, ng, stream));
   double err = 0.0;
-  CAMCAL_DRV_TRY(camcal_read_begin(glob + ng - 1, 1, 0, stream));
-  CAMCAL_DRV_TRY(camcal_read_end(&err, 1));
+  CAMCAL_DRV_TRY(rd.begin(glob + ng - 1, 1, 0, stream));
+  CAMCAL_DRV_TRY(rd.end(&err, 1));
   for (;;) {
     const int tri = 1 - cur;
     const double prev_err = err;
@@ -120,10 +120,10 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
         }
       }
       double back[8];                              // one wait for the three small records
-      CAMCAL_DRV_TRY(camcal_read_begin(stats, 5, 0, stream));
-      CAMCAL_DRV_TRY(camcal_read_begin(norms, 2, 5, stream));
-      CAMCAL_DRV_TRY(camcal_read_begin(glob_trial + ng - 1, 1, 7, stream));
-      CAMCAL_DRV_TRY(camcal_read_end(back, 8));
+      CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
+      CAMCAL_DRV_TRY(rd.begin(norms, 2, 5, stream));
+      CAMCAL_DRV_TRY(rd.begin(glob_trial + ng - 1, 1, 7, stream));
+      CAMCAL_DRV_TRY(rd.end(back, 8));
       for (int i = 0; i < 5; ++i) st[i] = back[i];
       nr[0] = back[5]; nr[1] = back[6];
       err = back[7];

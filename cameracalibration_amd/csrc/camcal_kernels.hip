@@ -1158,6 +1158,7 @@ __global__ __launch_bounds__(TPB) void k_peak_read4(const float* __restrict__ in
 inline int tiles_ok(const camcal_tiles* t) {
   if (!t || t->n_tiles <= 0 || t->n_slots != (int64_t)t->n_tiles * LANES) return 0;
   if (!t->tile_off || !t->tile_nmax || !t->lane_n) return 0;
+  if (t->lanes_per_view != 0 && t->lanes_per_view != 1 && t->lanes_per_view != 16 && t->lanes_per_view != 64) return 0;
   return 1;
 }
 // ---------------------------------------------------------------------------
@@ -1413,13 +1414,13 @@ inline int grid_persistent(const camcal_tiles* t) {
 // Lanes per view for this set: 1 (large sets: a lane walks its view), or 16 / 64 for
 // small planar sets.  The partial records of a grouped launch are one per wavefront
 // (n_tiles * G of them) and must fit the scratch every caller holds (camcal_scratch_len).
-int g_lanes_per_view = -1;                 // camcal_set_lanes_per_view
 constexpr int GROUP64_MAX_TILES = 32;      // <= 2048 views: one wavefront per view
 constexpr int GROUP16_MAX_TILES = 128;     // <= 8192 views: four views per wavefront
 inline int group_lanes(const camcal_tiles* t) {
-  if (!t->planar || g_lanes_per_view == 1) return 1;
-  if (g_lanes_per_view == 64) return t->n_tiles <= GROUP64_MAX_TILES ? 64 : 1;
-  if (g_lanes_per_view == 16) return t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
+  const int want = t->lanes_per_view;      // 0: by size
+  if (!t->planar || want == 1) return 1;
+  if (want == 64) return t->n_tiles <= GROUP64_MAX_TILES ? 64 : 1;
+  if (want == 16) return t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
   return t->n_tiles <= GROUP64_MAX_TILES ? 64 : t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
 }
 inline int grid_groups(const camcal_tiles* t, int G) { return (int)((t->n_slots * G + TPB - 1) / TPB); }
@@ -1460,11 +1461,6 @@ extern "C" {
 
 int camcal_version(void) { return 100; }
 
-int camcal_set_lanes_per_view(int lanes) {
-  if (lanes != -1 && lanes != 1 && lanes != 16 && lanes != 64) return CAMCAL_E_BADARG;
-  g_lanes_per_view = lanes;
-  return 0;
-}
 int camcal_n_intr(int model) { return model == CAMCAL_PINHOLE ? 9 : model == CAMCAL_FISHEYE ? 8 : CAMCAL_E_BADMODEL; }
 int camcal_glob_len(int model) {
   const int ni = camcal_n_intr(model);
@@ -2121,54 +2117,82 @@ int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void*
 }  // extern "C"
 
 // ---------------------------------------------------------------------------
-// Host-side solver loops (camcal_driver.h) and their two memory helpers.
+// Host-side solver loops (camcal_driver.h) and their memory helpers.
 namespace {
-// a small pinned landing buffer and an event per host thread: the copies are plain DMAs
-// (no staging), and waiting on the event instead of the stream lets kernels launched after
-// camcal_read_begin run while the host reads
+// Pinned landing buffers + events for the loops' read-backs: the copies are plain DMAs (no
+// staging), and waiting on the event instead of the stream lets kernels launched after
+// begin() run while the host reads.  One ReadBack per RUNNING solve, taken from a pool and
+// returned to it (the pool grows to the peak number of concurrent solves per device and is
+// kept until the process ends -- no per-thread state to leak).
 constexpr int READ_CAP = 64;
 struct ReadBack {
   double* pinned = nullptr;
   hipEvent_t ev = nullptr;
-  int dev = -1;                      // device the event belongs to
+  int dev = -1;
 };
-thread_local ReadBack g_rb;
-int read_back_init() {
-  if (!g_rb.pinned) HIP_TRY(hipHostMalloc((void**)&g_rb.pinned, READ_CAP * sizeof(double), hipHostMallocPortable));
-  int dev = 0;
-  HIP_TRY(hipGetDevice(&dev));
-  if (g_rb.ev && g_rb.dev != dev) {  // the calling thread moved to another device
-    (void)hipEventDestroy(g_rb.ev);
-    g_rb.ev = nullptr;
-  }
-  if (!g_rb.ev) {
-    HIP_TRY(hipEventCreateWithFlags(&g_rb.ev, hipEventDisableTiming));
-    g_rb.dev = dev;
-  }
-  return 0;
-}
-}  // namespace
+std::mutex g_rb_mu;
+std::vector<ReadBack*> g_rb_free;
 
-int camcal_read_begin(const double* src, int n, int offset, void* stream) {
-  if (n <= 0 || offset < 0 || offset + n > READ_CAP || !src) return CAMCAL_E_BADARG;
-  const int rc = read_back_init();
-  if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(g_rb.pinned + offset, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipEventRecord(g_rb.ev, s));
-  return 0;
-}
-
-int camcal_read_end(double* dst_host, int n_total) {
-  if (n_total <= 0 || n_total > READ_CAP || !dst_host || !g_rb.ev) return CAMCAL_E_BADARG;
-  HIP_TRY(hipEventSynchronize(g_rb.ev));
-  for (int i = 0; i < n_total; ++i) dst_host[i] = g_rb.pinned[i];
-  return 0;
-}
+struct camcal_reader {
+  ReadBack* rb = nullptr;
+  bool pending = false;
+  camcal_reader() = default;
+  camcal_reader(const camcal_reader&) = delete;
+  camcal_reader& operator=(const camcal_reader&) = delete;
+  ~camcal_reader() {
+    if (!rb) return;
+    if (pending) (void)hipEventSynchronize(rb->ev);       // never hand out a buffer a DMA may still write
+    std::lock_guard<std::mutex> lk(g_rb_mu);
+    g_rb_free.push_back(rb);
+  }
+  int acquire() {
+    if (rb) return 0;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> lk(g_rb_mu);
+      for (size_t i = 0; i < g_rb_free.size(); ++i)
+        if (g_rb_free[i]->dev == dev) {
+          rb = g_rb_free[i];
+          g_rb_free.erase(g_rb_free.begin() + (long)i);
+          return 0;
+        }
+    }
+    ReadBack* n = new ReadBack();
+    n->dev = dev;
+    hipError_t e = hipHostMalloc((void**)&n->pinned, READ_CAP * sizeof(double), hipHostMallocPortable);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      if (n->pinned) (void)hipHostFree(n->pinned);
+      delete n;
+      return (int)e;
+    }
+    rb = n;
+    return 0;
+  }
+  int begin(const double* src, int n, int offset, void* stream) {
+    if (n <= 0 || offset < 0 || offset + n > READ_CAP || !src) return CAMCAL_E_BADARG;
+    const int rc = acquire();
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(rb->pinned + offset, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(rb->ev, s));
+    pending = true;
+    return 0;
+  }
+  int end(double* dst_host, int n_total) {
+    if (n_total <= 0 || n_total > READ_CAP || !dst_host || !rb || !pending) return CAMCAL_E_BADARG;
+    HIP_TRY(hipEventSynchronize(rb->ev));
+    pending = false;
+    for (int i = 0; i < n_total; ++i) dst_host[i] = rb->pinned[i];
+    return 0;
+  }
+};
 
 int camcal_copy_doubles(double* dst, const double* src, int n, void* stream) {
   HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
+}  // namespace
 
 #include "camcal_driver.h"

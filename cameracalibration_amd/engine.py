@@ -53,7 +53,11 @@ class Engine:
     device : torch device; ``lib``: CamcalLib (default: the HIP build)
     """
 
-    def __init__(self, model, view_ptr, obj, img, device, lib=None):
+    #: lanes per view of the engines created from now on (camcal_tiles.lanes_per_view: 0 = by size,
+    #: 1 / 16 / 64 force a mapping); a plain class default so that tests and tools can pin a mapping
+    LANES_PER_VIEW = 0
+
+    def __init__(self, model, view_ptr, obj, img, device, lib=None, lanes_per_view=None):
         self.lib = lib if lib is not None else _lib.load()
         self.model = int(model)
         self.device = torch.device(device)
@@ -88,7 +92,8 @@ class Engine:
         self.S = S
         self.tiles = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off.data_ptr(),
                                 self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
-                                lay["n_tiles"], S, 0)
+                                lay["n_tiles"], S, 0,
+                                int(self.LANES_PER_VIEW if lanes_per_view is None else lanes_per_view))
         # pack on the device
         if isinstance(obj, np.ndarray):                     # host arrays: no device round trip for the flag
             planar = not np.asarray(obj).reshape(-1, 3)[:, 2].any()

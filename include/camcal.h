@@ -58,19 +58,21 @@ typedef struct camcal_tiles {
   int64_t        n_slots;    /* == 64 * n_tiles                                */
   int32_t        planar;     /* 1: every object point has Z == 0 (the Z rows are
                                 then never read); 0: general 3-D points        */
+  int32_t        lanes_per_view; /* how many lanes share one view in the per-view
+                                kernels: 0 = chosen by the size of the set (one lane per
+                                view for large sets -- the throughput mapping --, 16 or 64
+                                lanes per view for small planar sets of <= 8192 / <= 2048
+                                views, so that a production-sized call (20 ... 500 views,
+                                intrinsicCalib.py:102-105) spreads over the whole device
+                                instead of a handful of wavefronts); 1, 16 or 64 force a
+                                mapping where the set allows it (tests, measurements).
+                                Results differ between mappings only by the order of the
+                                sums.  A field of the set, not a process-wide switch:
+                                concurrent solves do not interfere.               */
 } camcal_tiles;
 
 /* Library version (major*10000 + minor*100 + patch). */
 int camcal_version(void);
-
-/* How many lanes share one view in the per-view kernels.  -1 (the default) chooses by
- * the size of the set: one lane per view for large sets (the throughput mapping), 16 or
- * 64 lanes per view for small planar sets (<= 8192 / <= 2048 views), so that a
- * production-sized call (20 ... 500 views, intrinsicCalib.py:102-105) spreads over the
- * whole device instead of a handful of wavefronts.  1, 16 or 64 force a mapping where
- * the set allows it (tests, measurements).  Process-wide, not thread-safe; results
- * differ between mappings only by the order of the sums.  No reference counterpart. */
-int camcal_set_lanes_per_view(int lanes);
 
 /* Number of doubles in the global normal-equation record of a model:
  *   [ U (NI(NI+1)/2) | b (NI) | cost ]  ->  camcal_glob_len
@@ -190,7 +192,7 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
  * (109 x 16384 + 192 doubles = 14.3 MB, held by every GPU the library runs on until the
  * process ends) instead of a caller-provided scratch; the call allocates and frees nothing.
  * Limit: n_tiles (x 64 or x 16 for the small planar sets that run several lanes per view,
- * see lanes_per_view) <= 16384 partial records, i.e. up to 1,048,576 views one lane per
+ * camcal_tiles.lanes_per_view) <= 16384 partial records, i.e. up to 1,048,576 views one lane per
  * view; larger sets return CAMCAL_E_TOOBIG.  glob / schur as in camcal_normal_eq_fused
  * (schur == glob + camcal_glob_len).  Nothing in the array has to start at zero (a launch
  * writes every entry it reads), but every call on one GPU shares the array: calls that

@@ -487,8 +487,8 @@ def calibrate_camera(object_points, image_points, image_size, K, D, flags=0,
     dist = np.zeros(5)
     dist[:Din.size] = Din.ravel()
     mask = _pinhole_mask(flags)
-    if Din.size == 4:
-        mask[8] = False
+    # a 4-coefficient guess: calibrateCameraRO pads it (prepareDistCoeffs) and keeps rowRange(0, 5), so k3
+    # is estimated unless CALIB_FIX_K3 and five coefficients are returned [cv-recall]
     if flags & CALIB_ZERO_TANGENT_DIST:
         dist[2] = dist[3] = 0.0
     intr0 = np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], dist])
@@ -533,7 +533,10 @@ def calibrate_camera(object_points, image_points, image_size, K, D, flags=0,
     intr, poses = unpack(p)
     rms = np.sqrt(err / views.total)
     Kout = np.array([[intr[0], 0, intr[2]], [0, intr[1], intr[3]], [0, 0, 1.0]])
-    Dout = intr[4:4 + Din.size].reshape(Din.shape)
+    if Din.size == 5:
+        Dout = intr[4:9].reshape(Din.shape)
+    else:
+        Dout = intr[4:9].reshape((1, 5) if (Din.ndim == 2 and Din.shape[0] == 1) else (5, 1))
     return rms, Kout, Dout, poses[:, :3].copy(), poses[:, 3:].copy(), dict(iters=iters, init_poses=poses0)
 
 

@@ -255,10 +255,7 @@ void rig_backsub(int n_cams, int64_t P, const double* Vp, const double* gp, cons
 extern "C" {
 int camcal_version(void) { return -100; }   // negative: emulator
 
-// the emulator always walks one view per lane; the setting is validated and ignored
-int camcal_set_lanes_per_view(int lanes) {
-  return (lanes == -1 || lanes == 1 || lanes == 16 || lanes == 64) ? 0 : CAMCAL_E_BADARG;
-}
+// the emulator always walks one view per lane; camcal_tiles.lanes_per_view is ignored
 int camcal_n_intr(int model) { return model == 0 ? 9 : model == 1 ? 8 : CAMCAL_E_BADMODEL; }
 int camcal_glob_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni + 1; }
 int camcal_schur_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni; }
@@ -547,19 +544,23 @@ int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 
 
 // Host-side solver loops: the same sequencing code as the HIP library, over this emulator's stages.
 #include <cstring>
-static thread_local double g_landing[64];
-int camcal_read_begin(const double* src, int n, int offset, void*) {
-  if (n <= 0 || offset < 0 || offset + n > 64 || !src) return CAMCAL_E_BADARG;
-  std::memcpy(g_landing + offset, src, (size_t)n * sizeof(double));
-  return 0;
-}
-int camcal_read_end(double* dst_host, int n_total) {
-  if (n_total <= 0 || n_total > 64 || !dst_host) return CAMCAL_E_BADARG;
-  std::memcpy(dst_host, g_landing, (size_t)n_total * sizeof(double));
-  return 0;
-}
+namespace {
+struct camcal_reader {
+  double landing[64];
+  int begin(const double* src, int n, int offset, void*) {
+    if (n <= 0 || offset < 0 || offset + n > 64 || !src) return CAMCAL_E_BADARG;
+    std::memcpy(landing + offset, src, (size_t)n * sizeof(double));
+    return 0;
+  }
+  int end(double* dst_host, int n_total) {
+    if (n_total <= 0 || n_total > 64 || !dst_host) return CAMCAL_E_BADARG;
+    std::memcpy(dst_host, landing, (size_t)n_total * sizeof(double));
+    return 0;
+  }
+};
 int camcal_copy_doubles(double* dst, const double* src, int n, void*) {
   std::memmove(dst, src, (size_t)n * sizeof(double));
   return 0;
 }
+}  // namespace
 #include "../../cameracalibration_amd/csrc/camcal_driver.h"

@@ -33,13 +33,11 @@ def dev():
 
 
 @pytest.fixture(params=[1, 16, 64], ids=["lane-per-view", "16-lanes-per-view", "64-lanes-per-view"])
-def mapping(request, dev):
+def mapping(request, dev, monkeypatch):
     """Run a small-set test under each mapping of views to lanes (include/camcal.h:
-    camcal_set_lanes_per_view); the default (-1, chosen by size) is restored afterwards."""
-    lib = _lib.load()
-    lib.check(lib.camcal_set_lanes_per_view(request.param), "camcal_set_lanes_per_view")
+    camcal_tiles.lanes_per_view; 0 = chosen by size is the default)."""
+    monkeypatch.setattr(Engine, "LANES_PER_VIEW", request.param)
     yield request.param
-    lib.check(lib.camcal_set_lanes_per_view(-1), "camcal_set_lanes_per_view")
 
 
 def sym(tri, n):
@@ -226,21 +224,16 @@ def test_automatic_mapping_at_its_size_boundaries(dev, nv):
     """The mapping chosen by size (64 lanes per view up to 32 tiles, 16 up to 128, one above)
     against one lane per view, on ragged sets either side of every boundary: the single-pass
     record, the stored blocks and a pose re-estimation."""
-    lib = _lib.load()
     P = synth.config("C3", n_views=nv)
     out = []
-    for mode in (1, -1):
-        lib.check(lib.camcal_set_lanes_per_view(mode), "camcal_set_lanes_per_view")
-        try:
-            E = Engine(1, P.view_ptr, P.obj, P.img, dev)
-            E.set_intr(0, P.intr_guess())
-            E.set_poses(0, P.poses_true.numpy())
-            E.normal_eq(0, 0, 1e-3, store_blocks=True, fused=True)
-            rec, W = E.rec.cpu().numpy().copy(), E.slots_to_views(E.W.T).copy()
-            E.pose_refine(0, 0, 20, 1e-10)
-            out.append((rec, W, E.get_poses(0), E.slots_to_views(E.iters).copy()))
-        finally:
-            lib.check(lib.camcal_set_lanes_per_view(-1), "camcal_set_lanes_per_view")
+    for mode in (1, 0):
+        E = Engine(1, P.view_ptr, P.obj, P.img, dev, lanes_per_view=mode)
+        E.set_intr(0, P.intr_guess())
+        E.set_poses(0, P.poses_true.numpy())
+        E.normal_eq(0, 0, 1e-3, store_blocks=True, fused=True)
+        rec, W = E.rec.cpu().numpy().copy(), E.slots_to_views(E.W.T).copy()
+        E.pose_refine(0, 0, 20, 1e-10)
+        out.append((rec, W, E.get_poses(0), E.slots_to_views(E.iters).copy()))
     (r1, w1, p1, i1), (r2, w2, p2, i2) = out
     assert np.abs(r1 - r2).max() <= 1e-11 * np.abs(r1).max()
     assert np.abs(w1 - w2).max() <= 1e-11 * np.abs(w1).max()

@@ -248,3 +248,41 @@ def test_pose_init_lands_in_basin(emu):
             E.pose_refine(0, 0, 20, 1e-10)
             want = np.stack([O.find_extrinsics_pinhole(o, i, g, max_iter=200) for o, i in zip(views.obj, views.img)])
             assert np.allclose(E.get_poses(0), want, rtol=1e-5, atol=1e-4)
+
+
+def test_four_coefficient_guess_is_padded_like_cv2(emu):
+    """cv2.calibrateCamera pads a 4-element distCoeffs to its 5-coefficient model, estimates k3 unless
+    CALIB_FIX_K3 and returns a NEW 5-element array in the input's orientation."""
+    P = synth.config("C1")
+    objs, imgs = P.as_lists()
+    for shape, want in (((4, 1), (5, 1)), ((1, 4), (1, 5)), ((4,), (5, 1))):
+        D4 = P.D_guess.ravel()[:4].reshape(shape).copy()
+        keep = D4.copy()
+        r = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), D4, flags=1, criteria=CRIT,
+                               _lib_override=emu, _device_override=CPU)
+        assert r[2].shape == want and r[2] is not D4 and np.array_equal(D4, keep)
+        assert abs(r[2].ravel()[4]) > 1e-3                        # k3 was estimated
+    o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess.ravel()[:4].reshape(4, 1), flags=1,
+                           criteria=CRIT, solver="dense")
+    assert o[2].shape == (5, 1) and abs(r[0] - o[0]) < 1e-9 and np.allclose(r[2].ravel(), o[2].ravel(), rtol=1e-6, atol=1e-9)
+    rf = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.ravel()[:4].copy(),
+                            flags=1 | cc.CALIB_FIX_K3, criteria=CRIT, _lib_override=emu, _device_override=CPU)
+    assert rf[2].shape == (5, 1) and rf[2][4, 0] == 0.0
+
+
+def test_degenerate_view_raises_and_names_it(emu):
+    """One view with collinear corners: the pose start has no answer (cv2 returns garbage / non-finite values
+    for the caller's checkRange); the drop-in raises `error` naming the view."""
+    for cfg, fn, fl in (("C2", cc.fisheye.calibrate, FE), ("C1", cc.calibrateCamera, 1)):
+        P = synth.config(cfg, n_views=12)
+        objs, imgs = P.as_lists()
+        o5 = objs[5].copy()
+        o5[:, 0, 1] = 0.0                                         # every corner on one board line ...
+        i5 = imgs[5].copy()
+        i5[:, 0, 1] = i5[0, 0, 1]                                 # ... and on one image line
+        i5[:, 0, 0] = i5[0, 0, 0] + o5[:, 0, 0]
+        objs[5], imgs[5] = o5, i5
+        with pytest.raises(cc.error) as ei:
+            fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT,
+               _lib_override=emu, _device_override=CPU)
+        assert "5" in str(ei.value)

@@ -9,6 +9,7 @@ from cameracalibration_amd import synth, _lib
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, -1]
 FE = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+from cameracalibration_amd.engine import Engine
 lib = _lib.load()
 cases = (("C1", 20), ("C2", 25), ("C2", 500), ("C2", 2000), ("C2", 8000))
 if len(sys.argv) > 3:
@@ -18,7 +19,7 @@ for cfg, nv in cases:
     objs, imgs = P.as_lists()
     ref = None
     for mode in modes:
-        lib.check(lib.camcal_set_lanes_per_view(mode), "mode")
+        Engine.LANES_PER_VIEW = max(mode, 0)       # -1 / 0: chosen by size
         ts = []
         for _ in range(reps + 1):
             torch.cuda.synchronize()
@@ -40,7 +41,7 @@ for cfg, nv in cases:
             msg = (f" | vs first mode: rms {abs(rms - ref[0]):.2e} K {np.abs(K - ref[1]).max() / ref[1].max():.2e}"
                    f" D {np.abs(D - ref[2]).max() / np.abs(ref[2]).max():.2e}")
         print(f"{cfg} {nv} views lanes/view {mode:3d}: median {np.median(ts[1:])*1e3:.2f} ms, iters {info.get('iters')}, rms {rms:.9f}{msg}", flush=True)
-lib.camcal_set_lanes_per_view(-1)
+Engine.LANES_PER_VIEW = 0
 if os.environ.get("CAMCAL_CPROFILE"):
     import cProfile, pstats
     P = synth.config("C2", n_views=500)
