@@ -10,11 +10,12 @@ HIPFLAGS_EXTRA ?= -mllvm -amdgpu-use-amdgpu-trackers=1
 all: lib hostemu oracle examples
 
 lib: $(CSRC)/libcamcal.so
-$(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h $(CSRC)/camcal_rig.h $(CSRC)/camcal_points.h include/camcal.h
+CSRC_HDRS := $(wildcard $(CSRC)/*.h) include/camcal.h
+$(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC_HDRS)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS_EXTRA) $< -o $@
 
 hostemu: tests/hostemu/libcamcal_hostemu.so
-tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC)/camcal_lane.h $(CSRC)/camcal_math.h $(CSRC)/camcal_rig.h $(CSRC)/camcal_points.h include/camcal.h
+tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC_HDRS)
 	g++ -O2 -std=c++17 -fPIC -shared $< -o $@
 
 oracle:

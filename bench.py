@@ -180,12 +180,13 @@ def solve_times(dev, with_cpu=True):
 
         def c4():
             info = {}
-            rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-7), cams=cams,
+            rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 100, 1e-7), cams=cams,
                               n_poses=R.n_poses, _info=info)
             return info
         ms, info = med(c4)
         out["C4_rig_4x10000_poses"] = {"ms": ms, "iterations": info["iters"], "observations": R.n_obs,
-                                        "note": "points already on the device"}
+                                        "note": "points already on the device; LM loop inside the library (camcal_rig_lm), "
+                                                "stops on eps = 1e-7, not on the iteration cap"}
         del R, cams
         torch.cuda.empty_cache()
         lib = _lib.load()

@@ -30,6 +30,24 @@ _TP = C.POINTER(Tiles)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
+class RigCam(C.Structure):
+    """struct camcal_rig_cam (include/camcal.h)."""
+    _fields_ = [("tiles", Tiles), ("slot_pose", C.c_void_p), ("pose_slot", C.c_void_p), ("pose", C.c_void_p),
+                ("V", C.c_void_p), ("W", C.c_void_p), ("g", C.c_void_p)]
+
+
+RIG_MAX_CAMS = 4
+
+
+class Rig(C.Structure):
+    """struct camcal_rig (include/camcal.h)."""
+    _fields_ = [("model", C.c_int32), ("n_cams", C.c_int32), ("P", C.c_int64), ("cam", RigCam * RIG_MAX_CAMS),
+                ("intr", C.c_void_p * 2), ("ext", C.c_void_p * 2), ("rig_pose", C.c_void_p * 2),
+                ("Vp", C.c_void_p * 2), ("gp", C.c_void_p * 2), ("Wp", C.c_void_p * 2), ("rec", C.c_void_p * 2),
+                ("Yt", C.c_void_p), ("z", C.c_void_p), ("dG", C.c_void_p), ("scratch", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
 class CommStruct(C.Structure):
     """struct camcal_comm (include/camcal.h)."""
     _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("ctx", C.c_void_p)]
@@ -64,12 +82,15 @@ _SIGNATURES = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_float)]),
-    "camcal_rig_compose": (C.c_int, [_TP, _P, _P, C.c_int64, _P, _P, _P]),
-    "camcal_rig_local_blocks": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "camcal_rig_assemble": (C.c_int, [_I, _TP, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "camcal_rig_pose_schur": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P]),
-    "camcal_rig_solve_reduced": (C.c_int, [_I, _I, _P, C.c_char_p, _D, _P, _P, _P, _P, _P, _P, _P]),
-    "camcal_rig_backsub": (C.c_int, [_I, _I, C.c_int64, _P, _P, _P, _D, _P, _P, _P, _P, _P, _P]),
+    "camcal_rig_rec_len": (C.c_int64, [_I, _I]),
+    "camcal_rig_scratch_len": (C.c_int64, [_I, _I, _P, C.c_int64]),
+    "camcal_rig_evaluate": (C.c_int, [_P, _I, _P]),
+    "camcal_rig_eliminate": (C.c_int, [_P, _I, _D, _P]),
+    "camcal_rig_solve": (C.c_int, [_P, _I, C.c_char_p, _D, _I, _P]),
+    "camcal_rig_backsub": (C.c_int, [_P, _I, _D, _I, _P]),
+    "camcal_rig_init": (C.c_int, [_P, _P, _P]),
+    "camcal_rig_lm": (C.c_int, [_P, C.c_char_p, _I, _D, _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32)]),
     "camcal_project_points": (C.c_int, [_I, C.c_int64, _P, _P, _P, _P, _P]),
     "camcal_reproj_err": (C.c_int, [_I, _TP, _P, _P, _I, _P, _P, _P, _P]),
     "camcal_undistort_points": (C.c_int, [_I, C.c_int64, _P, _P, _P, _P, _P]),

@@ -387,133 +387,6 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + tile, scratch_stride);
 }
 
-// ---------------------------------------------------------------------------
-// Rig kernels (see camcal_rig.h)
-__global__ __launch_bounds__(TPB) void k_rig_compose(int64_t S, const int32_t* __restrict__ slot_pose,
-                                                     const double* __restrict__ rig_pose, int64_t P,
-                                                     const double* __restrict__ ext, double* __restrict__ pose_out) {
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= S) return;
-  const int idx = slot_pose[slot];
-  double out[6] = {0, 0, 0, 0, 0, 1};
-  if (idx >= 0) {
-    double pp[6], e[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) { pp[c] = rig_pose[c * P + idx]; e[c] = ext[c]; }
-    rig_compose(pp, e, out);
-  }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) pose_out[c * S + slot] = out[c];
-}
-
-template <int NI>
-__global__ __launch_bounds__(TPB) void k_rig_assemble(int64_t S, int n_tiles, const int32_t* __restrict__ slot_pose,
-                                                      const double* __restrict__ rig_pose, int64_t P,
-                                                      const double* __restrict__ ext, const double* __restrict__ Vb,
-                                                      const double* __restrict__ Wb, const double* __restrict__ gb,
-                                                      double* __restrict__ Vp, double* __restrict__ gp,
-                                                      double* __restrict__ Wp, double* __restrict__ scratch) {
-  constexpr int NACC = NI * 6 + 21 + 6;
-  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
-  const int n_waves = gridDim.x * WPB;
-  const int lane = threadIdx.x & 63;
-  double acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
-  double e[6];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) e[c] = ext[c];
-  for (int tile = wave; tile < n_tiles; tile += n_waves) {
-    const int64_t slot = (int64_t)tile * LANES + lane;
-    const int idx = slot_pose[slot];
-    if (idx < 0) continue;
-    double pp[6], A[36], B[36], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) Vl[i] = Vb[i * S + slot];
-#pragma unroll
-    for (int i = 0; i < NI * 6; ++i) Wl[i] = Wb[i * S + slot];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gl[i] = gb[i * S + slot];
-    rig_chain(pp, e, A, B);
-    rig_assemble_view<NI>(Vl, Wl, gl, A, B, oV, og, oW, acc);
-#pragma unroll
-    for (int i = 0; i < 21; ++i) Vp[i * P + idx] = oV[i];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
-#pragma unroll
-    for (int i = 0; i < (NI + 6) * 6; ++i) Wp[i * P + idx] = oW[i];
-  }
-  wave_reduce_store<NACC>(acc, scratch, wave);
-}
-
-// blockIdx.y selects a chunk of RIG_SCHUR_CHUNK columns of Wp: the factorisation of the
-// pose block is cheap next to the latency of walking all n_cams * G columns in one thread
-constexpr int RIG_SCHUR_CHUNK = 8;
-template <int G>
-__global__ __launch_bounds__(TPB) void k_rig_pose_schur(int n_cams, int64_t P, const double* __restrict__ Vp_all,
-                                                        const double* __restrict__ gp_all,
-                                                        const double* __restrict__ Wp_all, double lam,
-                                                        double* __restrict__ Y, double* __restrict__ z) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  double U[21], g[6];
-  const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, g);
-  const int64_t ld = (int64_t)n_cams * G;
-  if (blockIdx.y == 0) {
-    if (ok) chol6_fwd(U, g);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) z[p * 6 + k] = ok ? g[k] : 0.0;
-  }
-  const int v0 = blockIdx.y * RIG_SCHUR_CHUNK;
-  const int v1 = v0 + RIG_SCHUR_CHUNK < (int)ld ? v0 + RIG_SCHUR_CHUNK : (int)ld;
-  for (int v = v0; v < v1; ++v) {                 // v = c * G + a
-    double y[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) y[k] = Wp_all[((int64_t)v * 6 + k) * P + p];
-    if (ok) chol6_fwd(U, y);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Y[(p * 6 + k) * ld + v] = ok ? y[k] : 0.0;
-  }
-}
-
-template <int G>
-__global__ __launch_bounds__(TPB) void k_rig_backsub(int n_cams, int64_t P, const double* __restrict__ Vp_all,
-                                                     const double* __restrict__ gp_all,
-                                                     const double* __restrict__ Wp_all, double lam,
-                                                     const double* __restrict__ dG, const double* __restrict__ pose_in,
-                                                     double* __restrict__ pose_out, double* __restrict__ scratch) {
-  const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
-  const int n_waves = gridDim.x * WPB;
-  const int lane = threadIdx.x & 63;
-  double acc[2] = {0.0, 0.0};
-  for (int64_t p = (int64_t)wave * LANES + lane; p < P; p += (int64_t)n_waves * LANES) {
-    double U[21], rhs[6], prev[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) prev[k] = pose_in[k * P + p];
-    const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, rhs);
-    if (ok) {
-      for (int c = 0; c < n_cams; ++c)
-        for (int a = 0; a < G; ++a) {
-          const double d = dG[c * G + a];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) rhs[k] -= Wp_all[(((int64_t)c * G + a) * 6 + k) * P + p] * d;
-        }
-      chol6_fwd(U, rhs);
-      chol6_bwd(U, rhs);
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const double d = ok ? rhs[k] : 0.0;
-      pose_out[k * P + p] = prev[k] - d;
-      acc[0] += d * d;
-      acc[1] += prev[k] * prev[k];
-    }
-  }
-  wave_reduce_store<2>(acc, scratch, wave);
-}
-
 __global__ __launch_bounds__(TPB) void k_finalize_strided(const double* __restrict__ scratch, int n_part, int stride,
                                                           double* __restrict__ out) {
   __shared__ double sh[TPB];
@@ -1276,135 +1149,6 @@ __global__ __launch_bounds__(TPB) void k_remap_u8(const unsigned char* __restric
   remap_pixel_u8(src, sw, sh, sstride, cn, ix, iy, fx, fy, cval, dst + (long long)i * dstride + (long long)j * cn);
 }
 
-// Reduced solve of the rig on one wavefront.  The system (n <= 64) is built and Jacobi-
-// scaled in LDS (camcal_rig.h: rig_solve_build / rig_solve_scale); the Cholesky
-// factorisation then runs with row i of the matrix in lane i's registers: the pivot and
-// the column entries l_jk a trailing update needs are v_readlane broadcasts with constant
-// lane and register numbers (the loops are fully unrolled), so a step costs no LDS round
-// trip and no barrier (202 -> 73 us at n = 50).  Rows / columns beyond n are identity padding.
-__device__ __forceinline__ double lane_bcast_c(double x, int src) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
-                          __builtin_amdgcn_readlane(__double2loint(x), src));
-}
-
-__global__ __launch_bounds__(64) void k_rig_solve_reduced(int NI, int n_cams, const double* __restrict__ rec,
-                                                          unsigned long long mask, double lam,
-                                                          const double* __restrict__ intr_in,
-                                                          const double* __restrict__ ext_in,
-                                                          double* __restrict__ intr_out, double* __restrict__ ext_out,
-                                                          double* __restrict__ dG, double* __restrict__ stats) {
-  __shared__ RigSolveWs w;
-  constexpr int N = RIG_MAXN;
-  const int lane = threadIdx.x, n = n_cams * (NI + 6);
-  // the entries of rig_solve_build, one per lane and trip (coalesced reads of C, several in flight)
-  {
-    const int G = NI + 6;
-    const int NU = NI * (NI + 1) / 2, NV = NU + NI + 1, NX = NI * 6 + 27;
-    const double* Cm = rec + (long long)n_cams * (NV + NX);
-    const double* d = Cm + (long long)n * n;
-#pragma unroll 4
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e - i * n;
-      const int c = i / G, a = i - c * G, cj = j / G, b = j - cj * G;
-      const double* glob = rec + (long long)c * (NV + NX);
-      const double* rx = glob + NV;
-      double v;
-      if (!((mask >> i) & 1ull) || !((mask >> j) & 1ull)) {
-        v = (i == j) ? 1.0 : 0.0;
-      } else {
-        v = 0.0;
-        if (c == cj) {
-          const int lo = a < b ? a : b, hi = a < b ? b : a;
-          if (hi < NI) v = glob[tri(NI, lo, hi)];
-          else if (lo < NI) v = rx[lo * 6 + (hi - NI)];
-          else v = rx[NI * 6 + tri(6, lo - NI, hi - NI)];
-          if (i == j) v *= 1.0 + lam;
-        }
-        v -= Cm[e];
-      }
-      w.A[i * RIG_LD + j] = v;
-    }
-    __syncthreads();
-    if (lane < n) {
-      const int c = lane / G, a = lane - c * G;
-      const double* glob = rec + (long long)c * (NV + NX);
-      const double* rx = glob + NV;
-      double r = 0.0;
-      if ((mask >> lane) & 1ull) r = (a < NI ? glob[NU + a] : rx[NI * 6 + 21 + (a - NI)]) - d[lane];
-      w.rhs[lane] = r;
-      const double dii = w.A[lane * RIG_LD + lane];
-      w.sc[lane] = dii > 0.0 ? 1.0 / sqrt(dii) : 1.0;
-    }
-    if (lane == 0) w.ok = 1;
-  }
-  __syncthreads();
-  rig_solve_scale(lane, 64, n, w);
-  __syncthreads();
-  double row[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j) row[j] = (lane < n && j < n) ? w.A[lane * RIG_LD + j] : (lane == j ? 1.0 : 0.0);
-  double y = lane < n ? w.rhs[lane] : 0.0;
-  double my_inv = 1.0;               // 1 / L_ii of this lane's row
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < n) {                     // uniform
-      const double p = lane_bcast_c(row[k], k);
-      const bool good = p > 0.0;
-      double rt;
-      const double rs = fast_rsqrt(good ? p : 1.0, rt);          // 1/sqrt(p) and sqrt(p), <= 2 ulp
-      const double inv = good ? rs : 0.0;
-      ok = ok && good;
-      const double lik = lane > k ? row[k] * inv : 0.0;          // column k of L below the diagonal
-      if (lane > k) row[k] = lik;
-      if (lane == k) { row[k] = good ? rt : 1.0; my_inv = good ? inv : 1.0; }
-#pragma unroll
-      for (int j = k + 1; j < N; ++j) row[j] = fma(-lik, lane_bcast_c(lik, j), row[j]);   // A_ij -= l_ik l_jk
-    }
-  }
-  // L y = rhs, column by column
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < n) {
-      const double yk = lane_bcast_c(y, k) * lane_bcast_c(my_inv, k);
-      if (lane == k) y = yk;
-      if (lane > k) y = fma(-row[k], yk, y);
-    }
-  }
-  // L^T x = y needs the columns of L: transpose through LDS
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < N; ++j) w.A[lane * RIG_LD + j] = row[j];
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < N; ++j) row[j] = w.A[j * RIG_LD + lane];   // row[j] = L_j,lane
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) {
-    if (k < n) {
-      const double xk = lane_bcast_c(y, k) * lane_bcast_c(my_inv, k);
-      if (lane == k) y = xk;
-      if (lane < k) y = fma(-row[k], xk, y);
-    }
-  }
-  // rig_solve_finish, one parameter per lane: out = in - dG, stats = [||dG||^2, ||globals_in||^2];
-  // a failed factorisation gives NaN so that the LM driver rejects the step
-  double s0 = 0.0, s1 = 0.0;
-  if (lane < n) {
-    const int G = NI + 6, c = lane / G, a = lane - c * G;
-    const double bad = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
-    const double dx = ((mask >> lane) & 1ull) ? y * w.sc[lane] + bad : 0.0;
-    dG[lane] = dx;
-    const double prev = a < NI ? intr_in[c * 16 + a] : ext_in[c * 6 + (a - NI)];
-    if (a < NI) intr_out[c * 16 + a] = prev - dx;
-    else ext_out[c * 6 + (a - NI)] = prev - dx;
-    s0 = dx * dx;
-    s1 = prev * prev;
-  }
-  s0 = wave_sum(s0);
-  s1 = wave_sum(s1);
-  if (lane == 0) { stats[0] = s0; stats[1] = s1; }
-}
-
 inline int grid_tiles(const camcal_tiles* t) { return (t->n_tiles + WPB - 1) / WPB; }
 inline int grid_persistent(const camcal_tiles* t) {
   const int g = grid_tiles(t);
@@ -1426,6 +1170,8 @@ inline int group_lanes(const camcal_tiles* t) {
 inline int grid_groups(const camcal_tiles* t, int G) { return (int)((t->n_slots * G + TPB - 1) / TPB); }
 
 }  // namespace
+
+#include "camcal_rig_kernels.h"
 
 // Scratch of camcal_normal_eq_fused_static: the partial records of one single-pass evaluation,
 // [NR + NS rows][partials] + the reduced values, for callers that cannot allocate.  The name
@@ -1805,105 +1551,6 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
   return rc;
 }
 
-int camcal_rig_compose(const camcal_tiles* tiles, const int32_t* slot_pose, const double* rig_pose, int64_t P,
-                       const double* ext, double* pose_out, void* stream) {
-  if (!tiles_ok(tiles) || !slot_pose || !rig_pose || P <= 0 || !ext || !pose_out) return CAMCAL_E_BADARG;
-  const int64_t S = tiles->n_slots;
-  hipLaunchKernelGGL(k_rig_compose, dim3((unsigned)((S + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, S,
-                     slot_pose, rig_pose, P, ext, pose_out);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int camcal_rig_local_blocks(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double* V,
-                            double* W, double* g, double* glob, double* scratch, void* stream) {
-  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !V || !W || !g || !glob || !scratch) return CAMCAL_E_BADARG;
-  const int ng = camcal_glob_len(model);
-  if (ng < 0) return ng;
-  const dim3 gr(grid_tiles(tiles)), b(TPB);
-  hipStream_t s = (hipStream_t)stream;
-  const int nt = tiles->n_tiles;
-  const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
-  const int G = group_lanes(tiles);
-  if (G > 1) {
-    const int np = nt * G;
-    const dim3 gg(grid_groups(tiles, G));
-    double* redg = scratch + (size_t)nr * np;
-#define LAUNCHG(M, GG) hipLaunchKernelGGL((k_normal_fused_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, 0.0, V, W, g, scratch, np, 1)
-    if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHG(PINHOLE, 64); else LAUNCHG(PINHOLE, 16); }
-    else { if (G == 64) LAUNCHG(FISHEYE, 64); else LAUNCHG(FISHEYE, 16); }
-#undef LAUNCHG
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize_strided, dim3(nr), dim3(TPB), 0, s, scratch, np, np, redg);
-    HIP_TRY(hipGetLastError());
-    if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, redg, glob, 0, 0);
-    else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, redg, glob, 0, 0);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  double* red = scratch + (size_t)nr * nt;
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P, true>), gr, b, 0, s, *tiles, intr, pose, 0.0, V, W, g, scratch, nt)
-  DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
-#undef LAUNCH
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_finalize_strided, dim3(nr), dim3(TPB), 0, s, scratch, nt, nt, red);
-  HIP_TRY(hipGetLastError());
-  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, 0, 0);
-  else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, 0, 0);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int camcal_rig_assemble(int model, const camcal_tiles* tiles, const int32_t* slot_pose, const double* rig_pose,
-                        int64_t P, const double* ext, const double* V, const double* W, const double* g, double* Vp,
-                        double* gp, double* Wp, double* rec_ext, double* scratch, void* stream) {
-  if (!tiles_ok(tiles) || !slot_pose || !rig_pose || P <= 0 || !ext || !V || !W || !g || !Vp || !gp || !Wp || !rec_ext ||
-      !scratch)
-    return CAMCAL_E_BADARG;
-  const int ni = camcal_n_intr(model);
-  if (ni < 0) return ni;
-  hipStream_t s = (hipStream_t)stream;
-  const int gp_ = grid_persistent(tiles);
-  if (ni == 9) hipLaunchKernelGGL(k_rig_assemble<9>, dim3(gp_), dim3(TPB), 0, s, tiles->n_slots, tiles->n_tiles, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, scratch);
-  else hipLaunchKernelGGL(k_rig_assemble<8>, dim3(gp_), dim3(TPB), 0, s, tiles->n_slots, tiles->n_tiles, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, scratch);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_finalize, dim3(ni * 6 + 27), dim3(TPB), 0, s, scratch, gp_ * WPB, rec_ext);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
-                          const double* Wp_all, double lam, double* Y, double* z, void* stream) {
-  const int ni = camcal_n_intr(model);
-  if (ni < 0) return ni;
-  if (n_cams <= 0 || P <= 0 || !Vp_all || !gp_all || !Wp_all || !Y || !z) return CAMCAL_E_BADARG;
-  const int n_cols = n_cams * (ni + 6);
-  const dim3 gr((unsigned)((P + TPB - 1) / TPB), (unsigned)((n_cols + RIG_SCHUR_CHUNK - 1) / RIG_SCHUR_CHUNK)), b(TPB);
-  hipStream_t s = (hipStream_t)stream;
-  if (ni == 9) hipLaunchKernelGGL(k_rig_pose_schur<15>, gr, b, 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, Y, z);
-  else hipLaunchKernelGGL(k_rig_pose_schur<14>, gr, b, 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, Y, z);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
-                       const double* Wp_all, double lam, const double* dG, const double* pose_in, double* pose_out,
-                       double* norms, double* scratch, void* stream) {
-  const int ni = camcal_n_intr(model);
-  if (ni < 0) return ni;
-  if (n_cams <= 0 || P <= 0 || !Vp_all || !gp_all || !Wp_all || !dG || !pose_in || !pose_out || !norms || !scratch)
-    return CAMCAL_E_BADARG;
-  int64_t nb = (P + TPB - 1) / TPB;
-  if (nb > MAX_WAVES / WPB) nb = MAX_WAVES / WPB;
-  hipStream_t s = (hipStream_t)stream;
-  if (ni == 9) hipLaunchKernelGGL(k_rig_backsub<15>, dim3((unsigned)nb), dim3(TPB), 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, dG, pose_in, pose_out, scratch);
-  else hipLaunchKernelGGL(k_rig_backsub<14>, dim3((unsigned)nb), dim3(TPB), 0, s, n_cams, P, Vp_all, gp_all, Wp_all, lam, dG, pose_in, pose_out, scratch);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_finalize, dim3(2), dim3(TPB), 0, s, scratch, (int)nb * WPB, norms);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 int camcal_project_points(int model, int64_t n, const double* xyz, const double* pose6, const double* intr,
                           double* uv, void* stream) {
   if (n < 0 || (n > 0 && (!xyz || !uv)) || !pose6 || !intr) return CAMCAL_E_BADARG;
@@ -1983,23 +1630,6 @@ int camcal_remap_u8(const unsigned char* src, int src_w, int src_h, int64_t src_
   hipStream_t s = (hipStream_t)stream;
   if (map_type == 0) hipLaunchKernelGGL(k_remap_u8<0>, g, b, 0, s, src, src_w, src_h, (long long)src_stride, channels, map1, map2, dst_w, dst_h, dst, (long long)dst_stride, (unsigned char)border_value);
   else hipLaunchKernelGGL(k_remap_u8<1>, g, b, 0, s, src, src_w, src_h, (long long)src_stride, channels, map1, map2, dst_w, dst_h, dst, (long long)dst_stride, (unsigned char)border_value);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uint8_t* mask_host, double lam,
-                             const double* intr_in, const double* ext_in, double* intr_out, double* ext_out,
-                             double* dG, double* stats, void* stream) {
-  const int ni = camcal_n_intr(model);
-  if (ni < 0) return ni;
-  if (n_cams <= 0 || n_cams * (ni + 6) > RIG_MAXN || !rec || !mask_host || !intr_in || !ext_in || !intr_out ||
-      !ext_out || !dG || !stats)
-    return CAMCAL_E_BADARG;
-  unsigned long long mask = 0;
-  for (int i = 0; i < n_cams * (ni + 6); ++i)
-    if (mask_host[i]) mask |= 1ull << i;
-  hipLaunchKernelGGL(k_rig_solve_reduced, dim3(1), dim3(64), 0, (hipStream_t)stream, ni, n_cams, rec, mask, lam,
-                     intr_in, ext_in, intr_out, ext_out, dG, stats);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2196,3 +1826,4 @@ int camcal_copy_doubles(double* dst, const double* src, int n, void* stream) {
 }  // namespace
 
 #include "camcal_driver.h"
+#include "camcal_rig_driver.h"

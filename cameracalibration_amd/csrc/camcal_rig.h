@@ -19,6 +19,8 @@
 // so J_pose = J_loc B, J_ext = J_loc A and every rig block is a 6x6 congruence
 // of the local blocks (done here, once per view).
 #pragma once
+#include <cmath>
+#include "../../include/camcal.h"
 #include "camcal_lane.h"
 
 namespace camcal {
@@ -188,7 +190,7 @@ CC_HD void rig_solve_build(int lane, int nl, int NI, int n_cams, const double* r
                            double lam, RigSolveWs& w) {
   const int G = NI + 6, n = n_cams * G;
   const int NU = NI * (NI + 1) / 2, NV = NU + NI + 1, NX = NI * 6 + 27;
-  const double* Cm = rec + (long long)n_cams * (NV + NX);
+  const double* Cm = rec + (long long)n_cams * (NV + NX) + 5;   // RigLayout::o_C
   const double* d = Cm + (long long)n * n;
   for (int i = lane; i < n; i += nl) {
     const int c = i / G, a = i - c * G;
@@ -281,5 +283,152 @@ CC_HD void rig_solve_finish(int NI, int n_cams, unsigned long long mask, RigSolv
   stats[0] = s0;
   stats[1] = s1;
 }
+
+// ---------------------------------------------------------------------------
+// Record layout of one parameter buffer (include/camcal.h: camcal_rig.rec)
+struct RigLayout {
+  int NI, G, n, NV, NX, per, rec_len, o_cost, o_norms, o_gstats, o_C, o_d, total;
+  CC_HD RigLayout(int ni, int n_cams) {
+    NI = ni; G = ni + 6; n = n_cams * G;
+    NV = ni * (ni + 1) / 2 + ni + 1; NX = ni * 6 + 27; per = NV + NX;
+    rec_len = n_cams * per;
+    o_cost = rec_len; o_norms = rec_len + 1; o_gstats = rec_len + 3;
+    o_C = rec_len + 5; o_d = o_C + n * n; total = o_d + n;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Initialisation of the camera-from-rig transforms.  A board pose p seen by cameras c and
+// k with per-view poses q_c, q_k (camera-from-board) gives one sample of T_c o T_k^-1:
+//   R_ck = R_pc R_pk^T,   t_ck = t_pc - R_ck t_pk.
+// out[0..8] = R_ck (row-major), out[9..11] = t_ck.
+CC_HD void rig_pair_terms(const double qc[6], const double qk[6], double out[12]) {
+  double Rc[9], Rk[9];
+  rodrigues(qc, Rc);
+  rodrigues(qk, Rk);
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j)
+      out[i * 3 + j] = Rc[i * 3] * Rk[j * 3] + Rc[i * 3 + 1] * Rk[j * 3 + 1] + Rc[i * 3 + 2] * Rk[j * 3 + 2];
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    out[9 + i] = qc[3 + i] - (out[i * 3] * qk[3] + out[i * 3 + 1] * qk[4] + out[i * 3 + 2] * qk[5]);
+}
+
+// Board pose in the rig frame from camera c's view of it: R_p = R_c^T R_pc, t_p = R_c^T (t_pc - t_c).
+CC_HD void rig_pose_from_cam(const double q[6], const double ext[6], double out[6]) {
+  double Rc[9], Rq[9], R[9];
+  rodrigues(ext, Rc);
+  rodrigues(q, Rq);
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rc[i] * Rq[j] + Rc[3 + i] * Rq[3 + j] + Rc[6 + i] * Rq[6 + j];
+  rot_to_rvec(R, out);
+  const double d[3] = {q[3] - ext[3], q[4] - ext[4], q[5] - ext[5]};
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i) out[3 + i] = Rc[i] * d[0] + Rc[3 + i] * d[1] + Rc[6 + i] * d[2];
+}
+
+// ---------------------------------------------------------------------------
+// Host side of the initialisation (runs once per solve on 13 n_cams^2 numbers).
+namespace righost {
+
+// nearest rotation to M (row-major 3x3): U V^T of its SVD with the determinant fixed,
+// by one-sided Jacobi (columns of M orthogonalised by plane rotations accumulated in V)
+inline void nearest_rotation(const double M[9], double R[9]) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) A[i] = M[i];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double a = 0, b = 0, c = 0;
+        for (int i = 0; i < 3; ++i) { a += A[i * 3 + p] * A[i * 3 + p]; b += A[i * 3 + q] * A[i * 3 + q]; c += A[i * 3 + p] * A[i * 3 + q]; }
+        off += c * c;
+        if (c * c <= 1e-300 || c * c <= 1e-32 * a * b) continue;
+        const double zeta = (b - a) / (2.0 * c);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < 3; ++i) {
+          const double x = A[i * 3 + p], y = A[i * 3 + q];
+          A[i * 3 + p] = cs * x - sn * y; A[i * 3 + q] = sn * x + cs * y;
+          const double vx = V[i * 3 + p], vy = V[i * 3 + q];
+          V[i * 3 + p] = cs * vx - sn * vy; V[i * 3 + q] = sn * vx + cs * vy;
+        }
+      }
+    if (off < 1e-300) break;
+  }
+  // A = U S (columns), singular values = column norms; smallest one last for the sign fix
+  double sv[3], U[9];
+  for (int j = 0; j < 3; ++j) sv[j] = std::sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+  int order[3] = {0, 1, 2};
+  for (int a = 0; a < 2; ++a)
+    for (int b = a + 1; b < 3; ++b)
+      if (sv[order[b]] > sv[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  for (int jj = 0; jj < 3; ++jj) {
+    const int j = order[jj];
+    const double inv = sv[j] > 0 ? 1.0 / sv[j] : 0.0;
+    for (int i = 0; i < 3; ++i) U[i * 3 + jj] = A[i * 3 + j] * inv;
+  }
+  double Vs[9];
+  for (int jj = 0; jj < 3; ++jj)
+    for (int i = 0; i < 3; ++i) Vs[i * 3 + jj] = V[i * 3 + order[jj]];
+  if (!(sv[order[2]] > 0)) {        // rank 2: complete U with the cross product of its first two columns
+    U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+  }
+  auto det3 = [](const double* X) {
+    return X[0] * (X[4] * X[8] - X[5] * X[7]) - X[1] * (X[3] * X[8] - X[5] * X[6]) + X[2] * (X[3] * X[7] - X[4] * X[6]);
+  };
+  const double sgn = det3(U) * det3(Vs) < 0 ? -1.0 : 1.0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = U[i * 3] * Vs[j * 3] + U[i * 3 + 1] * Vs[j * 3 + 1] + sgn * U[i * 3 + 2] * Vs[j * 3 + 2];
+}
+
+inline void rot_to_rvec_host(const double R[9], double r[3]) { rot_to_rvec(R, r); }
+
+// sums [c][k][13] = sum over shared poses of (R_ck (9), t_ck (3), 1)  ->  ext [n_cams][6].
+// Spanning tree from camera 0: repeatedly attach the camera outside the tree that shares
+// the most poses with a camera inside it.  Returns false if some camera shares none.
+inline bool ext_from_pair_sums(int n_cams, const double* sums, double* ext) {
+  double Rc[CAMCAL_RIG_MAX_CAMS][9], tc[CAMCAL_RIG_MAX_CAMS][3];
+  bool in[CAMCAL_RIG_MAX_CAMS] = {false, false, false, false};
+  for (int i = 0; i < 9; ++i) Rc[0][i] = (i % 4 == 0) ? 1.0 : 0.0;
+  tc[0][0] = tc[0][1] = tc[0][2] = 0.0;
+  in[0] = true;
+  for (int done = 1; done < n_cams; ++done) {
+    double best = 0.0;
+    int bc = -1, bk = -1;
+    for (int c = 0; c < n_cams; ++c) {
+      if (in[c]) continue;
+      for (int k = 0; k < n_cams; ++k) {
+        if (!in[k]) continue;
+        const double n = sums[(c * n_cams + k) * 13 + 12];
+        if (n > 0 && n > best) { best = n; bc = c; bk = k; }
+      }
+    }
+    if (bc < 0) return false;
+    const double* s = sums + (bc * n_cams + bk) * 13;
+    double R[9];
+    nearest_rotation(s, R);
+    const double t[3] = {s[9] / best, s[10] / best, s[11] / best};
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j)
+        Rc[bc][i * 3 + j] = R[i * 3] * Rc[bk][j] + R[i * 3 + 1] * Rc[bk][3 + j] + R[i * 3 + 2] * Rc[bk][6 + j];
+      tc[bc][i] = R[i * 3] * tc[bk][0] + R[i * 3 + 1] * tc[bk][1] + R[i * 3 + 2] * tc[bk][2] + t[i];
+    }
+    in[bc] = true;
+  }
+  for (int c = 0; c < n_cams; ++c) {
+    double r[3] = {0, 0, 0};
+    if (c > 0) rot_to_rvec_host(Rc[c], r);
+    for (int i = 0; i < 3; ++i) { ext[c * 6 + i] = c > 0 ? r[i] : 0.0; ext[c * 6 + 3 + i] = c > 0 ? tc[c][i] : 0.0; }
+  }
+  return true;
+}
+
+}  // namespace righost
 
 }  // namespace camcal

@@ -142,6 +142,10 @@ class Engine:
         self.status, self.iters = ints[:S], ints[S:]
 
     # -- plumbing ------------------------------------------------------------
+    def _comm_pools(self):
+        """Tensors a torch.distributed callback communicator may be asked to reduce parts of."""
+        return [self._pool]
+
     def _stream(self):
         if self.device.type == "cuda":
             return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

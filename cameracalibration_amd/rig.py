@@ -38,7 +38,6 @@ import torch
 from . import _lib
 from .engine import Engine
 from .solver import Comm, DBL_EPSILON
-from .synth import _rot_from_rvec, _rvec_from_rot
 
 
 def _tri_index(n):
@@ -52,7 +51,8 @@ def _tri_index(n):
 
 
 class RigEngine:
-    """Device state of one rank's share of the board poses.
+    """Device state of one rank's share of the board poses: the buffers of a
+    ``camcal_rig`` (include/camcal.h) and thin wrappers over its stage calls.
 
     cams: list (one per camera) of dict(pose_idx (n_c,), view_ptr (n_c+1,),
     obj (T_c,3), img (T_c,2)); ``n_poses`` = poses held by this rank."""
@@ -62,14 +62,16 @@ class RigEngine:
         self.model = int(model)
         self.device = dev = torch.device(device)
         self.n_cams = len(cams)
+        if not 1 <= self.n_cams <= _lib.RIG_MAX_CAMS:
+            raise ValueError("1 to %d cameras are supported" % _lib.RIG_MAX_CAMS)
         self.P = int(max(n_poses, 1))
         self.n_poses = int(n_poses)
         self.E = [Engine(model, c["view_ptr"], c["obj"], c["img"], dev, lib=self.lib) for c in cams]
         self.NI = self.E[0].NI
         self.G = self.NI + 6
         self.nG = self.n_cams * self.G
-        if self.nG > 64:
-            raise ValueError("at most 64 global parameters (4 cameras) are supported by the reduced solve")
+        if self.nG > 63:
+            raise ValueError("at most 63 global parameters (4 cameras) are supported by the reduced solve")
         self.NV = self.E[0].glob_len
         self.NX = self.NI * 6 + 27
         self.n_obs = sum(e.n_obs for e in self.E)
@@ -88,7 +90,7 @@ class RigEngine:
             sp[sv >= 0] = pi[sv[sv >= 0]]
             self.slot_pose.append(torch.from_numpy(sp).to(dev))
         self.seen = seen
-        nC, P, G = self.n_cams, self.P, self.G
+        nC, P, G, n = self.n_cams, self.P, self.G, self.nG
         self.intr = [torch.zeros(nC, 16, **f64), torch.zeros(nC, 16, **f64)]
         self.ext = [torch.zeros(nC, 6, **f64), torch.zeros(nC, 6, **f64)]
         self.rig_pose = [torch.zeros(6, P, **f64), torch.zeros(6, P, **f64)]
@@ -97,24 +99,48 @@ class RigEngine:
         self.Vp = [torch.zeros(nC, 21, P, **f64) for _ in range(2)]
         self.gp = [torch.zeros(nC, 6, P, **f64) for _ in range(2)]
         self.Wp = [torch.zeros(nC, G * 6, P, **f64) for _ in range(2)]
-        # per-camera records [U|b|cost | U_ie|U_ee|b_e] followed by [C|d]: one all-reduce
+        # rec[b] = [per-camera records | cost | norms | gstats | C | d] (include/camcal.h)
         self.rec_len = nC * (self.NV + self.NX)
-        self.rec = [torch.zeros(self.rec_len + self.nG * self.nG + self.nG, **f64) for _ in range(2)]
-        # Y^T Y is a (nG x 6P) x (6P x nG) product with a tiny output: split the long
-        # dimension into chunks so the library GEMM (batched) fills the device, then sum
-        self.chunk = 256
-        rows = (6 * P + self.chunk - 1) // self.chunk * self.chunk
-        self.Y = torch.zeros(rows, self.nG, **f64)          # rows beyond 6P stay zero
-        self.z = torch.zeros(rows, **f64)
-        self.dG = torch.zeros(self.nG, **f64)
-        self.small = torch.zeros(4, **f64)                   # [gstats | norms]: read back together
-        self.gstats = self.small[:2]
-        self.norms = self.small[2:]
-        self._cost_idx = torch.tensor([c * (self.NV + self.NX) + self.NV - 1 for c in range(nC)],
-                                      dtype=torch.long, device=dev)
-        self.scratch = torch.zeros(int(self.lib.camcal_scratch_len(self.model, 1)), **f64)
+        self.o_cost, self.o_norms, self.o_gstats = self.rec_len, self.rec_len + 1, self.rec_len + 3
+        self.o_C = self.rec_len + 5
+        total = int(self.lib.camcal_rig_rec_len(self.model, nC))
+        assert total == self.o_C + n * n + n
+        self.rec = [torch.zeros(total, **f64) for _ in range(2)]
+        self.Yt = torch.zeros(n * 6, P, **f64)
+        self.z = torch.zeros(6, P, **f64)
+        self.dG = torch.zeros(64, **f64)
+        nt = np.asarray([e.layout["n_tiles"] for e in self.E], dtype=np.int32)
+        self.scratch = torch.zeros(int(self.lib.camcal_rig_scratch_len(self.model, nC, nt.ctypes.data, P)), **f64)
+        S_all = sum(e.S for e in self.E)
+        self.status = torch.zeros(S_all, dtype=torch.int32, device=dev)
+        self.pose_slot = [torch.full((P,), -1, dtype=torch.int32, device=dev) for _ in range(nC)]
         self._tri_i = torch.from_numpy(_tri_index(self.NI)).to(dev)
         self._tri_6 = torch.from_numpy(_tri_index(6)).to(dev)
+        self._fill_struct()
+
+    def _fill_struct(self):
+        r = _lib.Rig()
+        r.model, r.n_cams, r.P = self.model, self.n_cams, self.P
+        for c, e in enumerate(self.E):
+            k = r.cam[c]
+            k.tiles = e.tiles
+            k.slot_pose = self.slot_pose[c].data_ptr()
+            k.pose_slot = self.pose_slot[c].data_ptr()
+            k.pose = e.pose[0].data_ptr()
+            k.V, k.W, k.g = e.Vs[0].data_ptr(), e.W.data_ptr(), e.gs[0].data_ptr()
+        for b in range(2):
+            r.intr[b], r.ext[b], r.rig_pose[b] = self.intr[b].data_ptr(), self.ext[b].data_ptr(), self.rig_pose[b].data_ptr()
+            r.Vp[b], r.gp[b], r.Wp[b] = self.Vp[b].data_ptr(), self.gp[b].data_ptr(), self.Wp[b].data_ptr()
+            r.rec[b] = self.rec[b].data_ptr()
+        r.Yt, r.z, r.dG = self.Yt.data_ptr(), self.z.data_ptr(), self.dG.data_ptr()
+        r.scratch, r.status = self.scratch.data_ptr(), self.status.data_ptr()
+        self.c_rig = r
+
+    def _swap(self):
+        """Buffer 1 becomes buffer 0 (the library reported its result there)."""
+        for buf in (self.intr, self.ext, self.rig_pose, self.Vp, self.gp, self.Wp, self.rec):
+            buf.reverse()
+        self._fill_struct()
 
     # -- plumbing --------------------------------------------------------------
     def _call(self, name, *args):
@@ -123,13 +149,16 @@ class RigEngine:
     def _stream(self):
         return self.E[0]._stream()
 
+    def _rp(self):
+        return C.byref(self.c_rig)
+
     def cam_rec(self, b, c):
         o = c * (self.NV + self.NX)
         return self.rec[b][o:o + self.NV], self.rec[b][o + self.NV:o + self.NV + self.NX]
 
     def cd(self, b):
         n = self.nG
-        return self.rec[b][self.rec_len:self.rec_len + n * n].view(n, n), self.rec[b][self.rec_len + n * n:]
+        return self.rec[b][self.o_C:self.o_C + n * n].view(n, n), self.rec[b][self.o_C + n * n:]
 
     def set_params(self, b, intr, ext, poses=None):
         ti = torch.zeros(self.n_cams, 16, dtype=torch.float64)
@@ -149,39 +178,19 @@ class RigEngine:
     # -- stages ------------------------------------------------------------------
     def evaluate(self, b):
         """Blocks of the whole rig at parameter buffer ``b`` -> rec[b], Vp/gp/Wp[b]."""
-        st = self._stream()
-        for c, e in enumerate(self.E):
-            glob, rext = self.cam_rec(b, c)
-            ext_c = self.ext[b][c]
-            intr_c = self.intr[b][c]
-            self._call("camcal_rig_compose", e._tp(), self.slot_pose[c].data_ptr(), self.rig_pose[b].data_ptr(),
-                       self.P, ext_c.data_ptr(), e.pose[0].data_ptr(), st)
-            self._call("camcal_rig_local_blocks", self.model, e._tp(), intr_c.data_ptr(), e.pose[0].data_ptr(),
-                       e.V.data_ptr(), e.W.data_ptr(), e.g.data_ptr(), glob.data_ptr(), e.scratch.data_ptr(), st)
-            self._call("camcal_rig_assemble", self.model, e._tp(), self.slot_pose[c].data_ptr(),
-                       self.rig_pose[b].data_ptr(), self.P, ext_c.data_ptr(), e.V.data_ptr(), e.W.data_ptr(),
-                       e.g.data_ptr(), self.Vp[b][c].data_ptr(), self.gp[b][c].data_ptr(),
-                       self.Wp[b][c].data_ptr(), rext.data_ptr(), e.scratch.data_ptr(), st)
+        self._call("camcal_rig_evaluate", self._rp(), int(b), self._stream())
 
     def eliminate(self, b, lam):
-        """Pose elimination at damping ``lam`` -> [C|d] of rec[b]."""
-        self._call("camcal_rig_pose_schur", self.model, self.n_cams, self.P, self.Vp[b].data_ptr(),
-                   self.gp[b].data_ptr(), self.Wp[b].data_ptr(), float(lam), self.Y.data_ptr(),
-                   self.z.data_ptr(), self._stream())
-        Cm, d = self.cd(b)
-        Yc = self.Y.view(-1, self.chunk, self.nG)
-        Yt = Yc.transpose(1, 2)
-        Cm.copy_(torch.matmul(Yt, Yc).sum(0))                 # batched library GEMM (rocBLAS fp64)
-        d.copy_(torch.matmul(Yt, self.z.view(-1, self.chunk, 1)).sum(0).view(-1))
+        """Pose elimination at damping ``lam`` -> [C|d] of rec[b] (Y^T Y on the matrix cores)."""
+        self._call("camcal_rig_eliminate", self._rp(), int(b), float(lam), self._stream())
 
     def cost(self, b):
-        return self.rec[b][self._cost_idx].sum()
+        return self.rec[b][self.o_cost]
 
     def trial_scalars(self, b):
         """(cost, [||dG||^2, ||globals||^2], [||d poses||^2, ||poses||^2]) of a trial step: one read-back."""
-        out = torch.cat([self.rec[b][self._cost_idx], self.small]).cpu().numpy()
-        n = self.n_cams
-        return float(out[:n].sum()), out[n:n + 2], out[n + 2:n + 4]
+        out = self.rec[b][self.o_cost:self.o_cost + 5].cpu().numpy()
+        return float(out[0]), out[3:5], out[1:3]
 
     def reduced_system(self, b, lam):
         """(M, rhs) over the n_cams*(NI+6) globals, diag(M) damped like CvLevMarq."""
@@ -205,125 +214,61 @@ class RigEngine:
 
     def solve(self, b, lam, free, out):
         """dG = M^-1 rhs on the free globals (``free``: boolean mask over the
-        n_cams*(NI+6) globals); parameters[out] = parameters[b] - dG.  Returns
-        (||dG||^2, ||globals||^2) as a 2-vector on the device."""
+        n_cams*(NI+6) globals); parameters[out] = parameters[b] - dG; gstats of rec[out]."""
         m = bytes(bytearray(int(bool(x)) for x in free))
-        self._call("camcal_rig_solve_reduced", self.model, self.n_cams, self.rec[b].data_ptr(), m, float(lam),
-                   self.intr[b].data_ptr(), self.ext[b].data_ptr(), self.intr[out].data_ptr(),
-                   self.ext[out].data_ptr(), self.dG.data_ptr(), self.gstats.data_ptr(), self._stream())
-        return self.gstats
+        self._call("camcal_rig_solve", self._rp(), int(b), m, float(lam), int(out), self._stream())
 
     def backsub(self, b, lam, out):
-        self._call("camcal_rig_backsub", self.model, self.n_cams, self.P, self.Vp[b].data_ptr(),
-                   self.gp[b].data_ptr(), self.Wp[b].data_ptr(), float(lam), self.dG.data_ptr(),
-                   self.rig_pose[b].data_ptr(), self.rig_pose[out].data_ptr(), self.norms.data_ptr(),
-                   self.scratch.data_ptr(), self._stream())
+        self._call("camcal_rig_backsub", self._rp(), int(b), float(lam), int(out), self._stream())
 
     # -- initialisation ----------------------------------------------------------
     def init_from_guess(self, comm):
-        """Per-camera pose initialisation at the guessed intrinsics (the
-        single-camera kernels), camera-from-rig transforms from the chordal mean
-        of T_pc o T_pk^-1 over shared poses, board poses from the
-        lowest-numbered camera that sees them.  Writes buffer 0."""
-        nC, P = self.n_cams, self.P
-        dv = self.device                  # the batched 3x3 algebra stays where the poses are
-        f64 = dict(dtype=torch.float64, device=dv)
-        Rpc = torch.zeros(nC, P, 3, 3, **f64)
-        tpc = torch.zeros(nC, P, 3, **f64)
-        vis = torch.zeros(nC, P, dtype=torch.bool, device=dv)
-        for c, e in enumerate(self.E):
-            e.intr[0].copy_(self.intr[0][c])
-            e.pose_init(0, 0)
-            e.pose_refine(0, 0, 20, 1e-10)
-            sp = self.slot_pose[c]
-            ok = sp >= 0
-            pose = e.pose[0].t()[ok]
-            idx = sp[ok].long()
-            Rpc[c, idx] = _rot_from_rvec(pose[:, :3])
-            tpc[c, idx] = pose[:, 3:]
-            vis[c, idx] = True
-        sums = torch.zeros(nC, nC, 13, **f64)
-        for c in range(nC):
-            for k in range(nC):
-                if c == k:
-                    continue
-                both = (vis[c] & vis[k]).to(torch.float64)           # weights instead of a gather
-                Rck = Rpc[c] @ Rpc[k].transpose(1, 2)
-                tck = tpc[c] - torch.einsum("pij,pj->pi", Rck, tpc[k])
-                sums[c, k, :9] = (Rck * both[:, None, None]).sum(0).reshape(-1)
-                sums[c, k, 9:12] = (tck * both[:, None]).sum(0)
-                sums[c, k, 12] = both.sum()
-        sums = comm.allreduce(sums).cpu()
-        extR = {0: (torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64))}
-        while len(extR) < nC:
-            best = None
-            for c in range(nC):
-                if c in extR:
-                    continue
-                for k in sorted(extR):
-                    n = float(sums[c, k, 12])
-                    if n > 0 and (best is None or n > best[0]):
-                        best = (n, c, k)
-            if best is None:
-                raise ValueError("a camera shares no board pose with the rest of the rig")
-            n, c, k = best
-            U, _, Vt = torch.linalg.svd(sums[c, k, :9].view(3, 3))
-            R = U @ Vt
-            if torch.linalg.det(R) < 0:
-                R = U @ torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64)) @ Vt
-            t = sums[c, k, 9:12] / n
-            Rk, tk = extR[k]
-            extR[c] = (R @ Rk, R @ tk + t)
-        ext = torch.zeros(nC, 6, dtype=torch.float64)
-        for c in range(1, nC):
-            ext[c, :3] = _rvec_from_rot(extR[c][0][None])[0]
-            ext[c, 3:] = extR[c][1]
-        # board poses from the lowest-numbered camera that sees them: all candidates at once
-        first = torch.full((P,), nC, dtype=torch.long, device=dv)
-        for c in range(nC - 1, -1, -1):
-            first = torch.where(vis[c], torch.full_like(first, c), first)
-        Rall = torch.stack([extR[c][0] for c in range(nC)]).to(dv)      # (nC, 3, 3)
-        tall = torch.stack([extR[c][1] for c in range(nC)]).to(dv)      # (nC, 3)
-        seen = first < nC
-        cam = first.clamp_max(nC - 1)
-        ar = torch.arange(P, device=dv)
-        Rp = Rall[cam].transpose(1, 2) @ Rpc[cam, ar]                    # R_c^T R_pc
-        tp = torch.einsum("pji,pj->pi", Rall[cam], tpc[cam, ar] - tall[cam])   # R_c^T (t_pc - t_c)
-        poses = torch.zeros(P, 6, **f64)
-        poses[:, 5] = 1.0
-        if bool(seen.any()):
-            cand = torch.cat([_rvec_from_rot(Rp), tp], dim=1)
-            poses = torch.where(seen[:, None], cand, poses)
-        self.ext[0].copy_(ext.to(dv))
-        self.rig_pose[0].copy_(poses.t().contiguous())
+        """camcal_rig_init: per-camera pose initialisation at the guessed intrinsics,
+        camera-from-rig transforms from the chordal mean of T_pc o T_pk^-1 over shared
+        poses, board poses from the lowest-numbered camera that sees them.  Writes buffer 0."""
+        try:
+            self._call("camcal_rig_init", self._rp(), comm.handle(self), self._stream())
+        except _lib.CamcalError as exc:
+            if "status -1" in str(exc):
+                raise ValueError("a camera shares no board pose with the rest of the rig") from exc
+            raise
+
+    def _comm_pools(self):
+        """Tensors a torch.distributed callback communicator may be asked to reduce parts of."""
+        return [self.rec[0], self.rec[1], self.scratch]
 
 
 def lm_rig(R, free, max_iter, eps, comm=None, log=None):
     """CvLevMarq::updateAlt over the rig (same control flow as
     solver.lm_pinhole).  Buffer 0 holds the starting point and, on return, the
-    result.  Returns (errNorm2, iterations)."""
+    result.  Returns (errNorm2, iterations).  Sequenced by the library
+    (camcal_rig_lm) unless the iteration log is asked for."""
     comm = comm or Comm(enabled=False)
     max_iter = int(min(max(max_iter, 1), 1000))
     eps = max(float(eps), DBL_EPSILON)
     free = np.asarray(free, dtype=bool)
+    if log is None:
+        m = bytes(bytearray(int(bool(x)) for x in free))
+        err, its, cur = C.c_double(0.0), C.c_int32(0), C.c_int32(0)
+        R._call("camcal_rig_lm", R._rp(), m, max_iter, eps, comm.handle(R), R._stream(), C.byref(err), C.byref(its),
+                C.byref(cur))
+        if cur.value == 1:
+            R._swap()
+        return float(err.value), int(its.value)
     lam_lg10 = -3
     cur, tri = 0, 1
     R.evaluate(cur)
-    comm.allreduce(R.rec[cur][:R.rec_len])
-    err = float(R.cost(cur).item()) if comm.enabled else R.trial_scalars(cur)[0]
+    comm.allreduce(R.rec[cur][:R.o_cost + 1])
+    err = float(R.cost(cur).item())
     iters = 0
 
     def step(lam):
         R.eliminate(cur, lam)
-        comm.allreduce(R.rec[cur][R.rec_len:])
-        gn = R.solve(cur, lam, free, tri)
+        comm.allreduce(R.rec[cur][R.o_C:])
+        R.solve(cur, lam, free, tri)
         R.backsub(cur, lam, tri)
-        comm.allreduce(R.norms)
         R.evaluate(tri)
-        comm.allreduce(R.rec[tri][:R.rec_len])
-        if comm.enabled:
-            out = torch.cat([R.cost(tri).reshape(1), gn, R.norms]).cpu().numpy()
-            return float(out[0]), out[1:3], out[3:5]
+        comm.allreduce(R.rec[tri][:R.o_gstats])
         return R.trial_scalars(tri)
 
     while True:
@@ -337,11 +282,12 @@ def lm_rig(R, free, max_iter, eps, comm=None, log=None):
         lam_lg10 = max(lam_lg10 - 1, -16)
         iters += 1
         rel = math.sqrt(gn[0] + pn[0]) / math.sqrt(gn[1] + pn[1])
-        for buf in (R.intr, R.ext, R.rig_pose, R.Vp, R.gp, R.Wp, R.rec):
-            buf[cur], buf[tri] = buf[tri], buf[cur]
+        cur, tri = tri, cur
         if log is not None:
             log.append(dict(iter=iters, err=err, rel=rel, lam_lg10=lam_lg10))
         if iters >= max_iter or rel < eps:
+            if cur == 1:
+                R._swap()
             return err, iters
 
 
@@ -427,7 +373,7 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
         maxc = 1000
     if not ctype & 2:
         eps = DBL_EPSILON
-    log = [] if _info is not None else None
+    log = [] if (_info is not None and _info.get("log") is True) else None
     init_state = R.get_params(0) if _info is not None else None
     err, iters = lm_rig(R, free.reshape(-1), maxc, eps, comm=comm, log=log)
     n_total = comm.total(R.n_obs, dev)

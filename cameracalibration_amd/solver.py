@@ -107,23 +107,24 @@ class Comm:
         return out
 
     def _torch_handle(self, E):
-        """Callback communicator: the buffers the loops reduce are slices of the engine's pool."""
-        pool = E._pool
-        base, nbytes = pool.data_ptr(), pool.numel() * 8
+        """Callback communicator: the buffers the loops reduce are slices of tensors the
+        engine owns (``E._comm_pools()``)."""
+        pools = [(t.data_ptr(), t.numel() * 8, t) for t in E._comm_pools()]
         group = self.group
 
         def cb(ctx, buf, n, stream):
             try:
-                off = int(buf) - base
-                if off < 0 or off % 8 or off + 8 * n > nbytes:
-                    return -1
-                dist.all_reduce(pool[off // 8: off // 8 + n], op=dist.ReduceOp.SUM, group=group)
-                return 0
+                for base, nbytes, t in pools:
+                    off = int(buf) - base
+                    if 0 <= off and off % 8 == 0 and off + 8 * n <= nbytes:
+                        dist.all_reduce(t.view(-1)[off // 8: off // 8 + n], op=dist.ReduceOp.SUM, group=group)
+                        return 0
+                return -1
             except Exception:          # never unwind through the C frames
                 return -5
         fn = _lib.ALLREDUCE_FN(cb)
         st = _lib.CommStruct(fn, None)
-        self._keep.append((fn, st, pool))
+        self._keep.append((fn, st, pools))
         return C.pointer(st)
 
     def handle(self, E):

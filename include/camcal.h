@@ -276,50 +276,85 @@ int camcal_time_stage(int stage, int reps, int model, const camcal_tiles* tiles,
 
 /* ---- Multi-camera rig (BASELINE.json config 4; no reference counterpart: the tool
  * calibrates its cameras one after another, controller_internal_calibration.py:375-399).
- * Residual proj_c(R_c (R_p X + t_p) + t_c) - obs; each camera is an ordinary packed
- * view set whose per-slot pose is the composed transform.  slot_pose[s] = board-pose
- * index of slot s (-1 padding); rig_pose [6][P]; ext [6] = (r_c, t_c) on the device. */
+ * Residual proj_c(R_c (R_p X + t_p) + t_c) - obs, camera 0 = rig frame.  Unknowns ("globals",
+ * n = n_cams * (NI + 6) <= 63, camera-major: intrinsics then the camera-from-rig (r_c, t_c)) and
+ * one 6-dof pose per board placement.  Each camera is an ordinary packed view set; a view's
+ * pose is the composed transform.  Everything below is reachable from this header alone:
+ * fill a camcal_rig with device buffers, camcal_rig_init, camcal_rig_lm.
+ *
+ * Parameter and block buffers come in pairs (index b = 0 / 1: current / trial point).
+ * rec[b] (camcal_rig_rec_len doubles) =
+ *   [ per camera: glob (camcal_glob_len: U|b|cost) | U_ie (NI*6) | U_ee (21) | b_e (6) ]
+ *   [ cost (sum over the cameras) | norms (2: ||d poses||^2, ||poses||^2) ]      <- summed over ranks with the records
+ *   [ gstats (2: ||dG||^2, ||globals||^2) ]                                     <- identical on every rank
+ *   [ C (n x n) | d (n) ]                                                        <- summed over ranks on their own */
+#define CAMCAL_RIG_MAX_CAMS 4
 
-/* composed pose (R_c R_p, R_c t_p + t_c) of every slot of one camera */
-int camcal_rig_compose(const camcal_tiles* tiles, const int32_t* slot_pose, const double* rig_pose,
-                       int64_t P, const double* ext, double* pose_out, void* stream);
+typedef struct camcal_rig_cam {
+  camcal_tiles   tiles;      /* this camera's views, packed as for a single camera          */
+  const int32_t* slot_pose;  /* [n_slots] board pose seen in each slot, -1 = padding        */
+  int32_t*       pose_slot;  /* [P] workspace of camcal_rig_init: slot of a pose, -1 unseen */
+  double*        pose;       /* [6][n_slots] workspace of camcal_rig_init (per-view poses)  */
+  double*        V;          /* [21][n_slots]   workspace: blocks of a view in the local    */
+  double*        W;          /* [NI*6][n_slots]   tangent frame of its composed pose        */
+  double*        g;          /* [6][n_slots]                                                */
+} camcal_rig_cam;
 
-/* single-pass evaluation of one camera in the LOCAL tangent frame of the composed
- * poses: glob = [U|b|cost] of that camera's intrinsics, V, W, g per slot */
-int camcal_rig_local_blocks(int model, const camcal_tiles* tiles, const double* intr,
-                            const double* pose, double* V, double* W, double* g, double* glob,
-                            double* scratch, void* stream);
+typedef struct camcal_rig {
+  int32_t model, n_cams;
+  int64_t P;                 /* board poses held by this process                            */
+  camcal_rig_cam cam[CAMCAL_RIG_MAX_CAMS];
+  double* intr[2];           /* [n_cams][16]                                                */
+  double* ext[2];            /* [n_cams][6]  (r_c, t_c); camera 0 stays zero                */
+  double* rig_pose[2];       /* [6][P]                                                      */
+  double* Vp[2];             /* [n_cams][21][P]        pose blocks per camera               */
+  double* gp[2];             /* [n_cams][6][P]                                              */
+  double* Wp[2];             /* [n_cams][(NI+6)*6][P]  globals x pose                       */
+  double* rec[2];            /* camcal_rig_rec_len                                          */
+  double* Yt;                /* [n*6][P]  U^-T Wp^T, pose index fastest                     */
+  double* z;                 /* [6][P]    U^-T g                                            */
+  double* dG;                /* [64]                                                        */
+  double* scratch;           /* camcal_rig_scratch_len doubles                              */
+  int32_t* status;           /* [sum of n_slots] pose-initialisation status (may be NULL)   */
+} camcal_rig;
 
-/* chain rule to the rig parameters for one camera: per board pose Vp [21][P],
- * gp [6][P], Wp [(NI+6)*6][P] (rows: intrinsics then extrinsics) and rec_ext =
- * [U_ie (NI*6) | U_ee (21) | b_e (6)].  Only the poses this camera sees are written:
- * the caller zeroes Vp, gp, Wp ONCE (which poses a camera sees never changes), so the
- * entries of unseen poses stay zero through every evaluation. */
-int camcal_rig_assemble(int model, const camcal_tiles* tiles, const int32_t* slot_pose,
-                        const double* rig_pose, int64_t P, const double* ext, const double* V,
-                        const double* W, const double* g, double* Vp, double* gp, double* Wp,
-                        double* rec_ext, double* scratch, void* stream);
+int64_t camcal_rig_rec_len(int model, int n_cams);
+/* n_tiles_host: HOST array [n_cams] of the cameras' tile counts */
+int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_host, int64_t P);
 
-/* per board pose: V = sum_c Vp_c (diag*(1+lam)) = U^T U;  Y [6P][n_cams*(NI+6)] =
- * U^-T Wp^T and z [6P] = U^-T g, so that C = Y^T Y and d = Y^T z (library GEMM).
- * *_all arrays are the per-camera arrays of camcal_rig_assemble back to back. */
-int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp_all,
-                          const double* gp_all, const double* Wp_all, double lam, double* Y,
-                          double* z, void* stream);
+/* Blocks of the whole rig at parameter buffer b: per camera the single-pass evaluation of
+ * its views at the composed poses (local tangent frame), then the point-independent 6x6
+ * chain rule to the rig parameters: rec[b] records + cost, Vp/gp/Wp[b].  The caller zeroes
+ * Vp, gp, Wp ONCE (which poses a camera sees never changes; unseen entries stay zero). */
+int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream);
 
-/* reduced solve over the n_cams*(NI+6) <= 64 globals from rec = [per camera: glob | rec_ext]
- * [C | d] (C = Y^T Y, d = Y^T z): diag damped by (1+lam), parameters with mask_host[i] == 0
- * held, Jacobi-scaled Cholesky on one wavefront; intr_out [n_cams][16] / ext_out [n_cams][6]
- * = in - dG; stats = [||dG||^2, ||globals_in||^2]; NaN step if the matrix is not positive */
-int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uint8_t* mask_host,
-                             double lam, const double* intr_in, const double* ext_in,
-                             double* intr_out, double* ext_out, double* dG, double* stats,
-                             void* stream);
+/* Pose elimination at damping lam: per board pose V = sum_c Vp_c (diag*(1+lam)) = U^T U,
+ * Yt = U^-T Wp^T, z = U^-T g; then C = Y^T Y and d = Y^T z on the matrix cores
+ * (v_mfma_f64_16x16x4: the one dense fp64 contraction of this path, (6P x n)^T (6P x n)),
+ * summed in a fixed order -> [C | d] of rec[b]. */
+int camcal_rig_eliminate(const camcal_rig* rig, int b, double lam, void* stream);
 
-/* d_p = V'^-1 (g_p - Wp^T dG), pose_out = pose_in - d_p; norms as camcal_backsub */
-int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp_all, const double* gp_all,
-                       const double* Wp_all, double lam, const double* dG, const double* pose_in,
-                       double* pose_out, double* norms, double* scratch, void* stream);
+/* Reduced solve over the globals from rec[b]: diag damped by (1+lam), parameters with
+ * mask_host[i] == 0 held, Jacobi-scaled Cholesky on one wavefront; intr/ext[out] =
+ * intr/ext[b] - dG; gstats of rec[out]; NaN step if the matrix is not positive. */
+int camcal_rig_solve(const camcal_rig* rig, int b, const uint8_t* mask_host, double lam, int out, void* stream);
+
+/* d_p = V'^-1 (g_p - Wp^T dG), rig_pose[out] = rig_pose[b] - d_p; norms of rec[out]. */
+int camcal_rig_backsub(const camcal_rig* rig, int b, double lam, int out, void* stream);
+
+/* Starting point into buffer 0 from intr[0] (the guesses): per-camera pose initialisation
+ * and refinement (the single-camera kernels), camera-from-rig transforms from the chordal
+ * mean of T_pc o T_pk^-1 over shared poses (spanning tree from camera 0 by shared-pose
+ * count; the pair sums are summed over the ranks), board poses from the lowest-numbered
+ * camera that sees them.  CAMCAL_E_BADARG if a camera shares no pose with the rest. */
+int camcal_rig_init(const camcal_rig* rig, const camcal_comm* comm, void* stream);
+
+/* CvLevMarq::updateAlt over the rig (the control flow of camcal_pinhole_lm) from buffer 0;
+ * current_out_host = buffer that holds the result.  err_out_host = sum of squared
+ * residuals over all ranks. */
+int camcal_rig_lm(const camcal_rig* rig, const uint8_t* mask_host, int max_iter, double eps,
+                  const camcal_comm* comm, void* stream, double* err_out_host,
+                  int32_t* iterations_out_host, int32_t* current_out_host);
 
 /* ---- Point-level operations either side of the solver ---- */
 

@@ -161,70 +161,80 @@ static void cross_schur(const camcal_tiles* t, const double* intr, const double*
     }
   for (int i = 0; i < NS; ++i) out[i] = acc[i];
 }
+// ---- rig (include/camcal.h "Multi-camera rig"): the same per-lane bodies, looped -------------
 template <int MODEL>
-void rig_local_blocks(const camcal_tiles* t, const double* intr, const double* pose, double* V, double* W, double* g,
-                      double* glob) {
+void rig_eval_cam(const camcal_rig* rg, int b, int cam, double* red) {
   constexpr int NI = MT<MODEL>::NI, NR = IntrAcc<MODEL>::NR;
+  const camcal_rig_cam& k = rg->cam[cam];
+  const camcal_tiles* t = &k.tiles;
   const int64_t S = t->n_slots;
   std::vector<double> tot(NR, 0.0);
+  const double* I = rg->intr[b] + cam * 16;
+  const double* e = rg->ext[b] + cam * 6;
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
-      double p[6];
-      load_pose(pose, S, slot, p);
+      double p[6] = {0, 0, 0, 0, 0, 1};
+      const int idx = k.slot_pose[slot];
+      if (idx >= 0) {
+        double pp[6];
+        for (int c = 0; c < 6; ++c) pp[c] = rg->rig_pose[b][c * rg->P + idx];
+        rig_compose(pp, e, p);
+      }
       ViewAcc<MODEL> acc;
       IntrAcc<MODEL> gacc;
       gacc.zero();
-      if (t->planar) lane_normal_fused<MODEL, true, true>(lane_tile(t, tile, lane), intr, p, acc, gacc);
-      else lane_normal_fused<MODEL, false, true>(lane_tile(t, tile, lane), intr, p, acc, gacc);
-      for (int e = 0; e < 21; ++e) V[e * S + slot] = acc.V[e];
-      for (int e = 0; e < NI * 6; ++e) W[e * S + slot] = acc.W[e];
-      for (int e = 0; e < 6; ++e) g[e * S + slot] = acc.g[e];
+      if (t->planar) lane_normal_fused<MODEL, true, true>(lane_tile(t, tile, lane), I, p, acc, gacc);
+      else lane_normal_fused<MODEL, false, true>(lane_tile(t, tile, lane), I, p, acc, gacc);
+      for (int q = 0; q < 21; ++q) k.V[q * S + slot] = acc.V[q];
+      for (int q = 0; q < NI * 6; ++q) k.W[q * S + slot] = acc.W[q];
+      for (int q = 0; q < 6; ++q) k.g[q * S + slot] = acc.g[q];
       for (int i = 0; i < NR; ++i) tot[i] += gacc.v[i];
     }
-  IntrAcc<MODEL>::expand(tot.data(), glob);
+  for (int i = 0; i < NR; ++i) red[i] = tot[i];
 }
 
 template <int NI>
-void rig_assemble(const camcal_tiles* t, const int32_t* slot_pose, const double* rig_pose, int64_t P, const double* ext,
-                  const double* Vb, const double* Wb, const double* gb, double* Vp, double* gp, double* Wp, double* rec) {
+void rig_assemble_cam(const camcal_rig* rg, int b, int cam, double* rec_ext) {
   constexpr int NACC = NI * 6 + 27;
-  const int64_t S = t->n_slots;
+  const camcal_rig_cam& k = rg->cam[cam];
+  const int64_t S = k.tiles.n_slots, P = rg->P;
   double acc[NACC];
   for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  double* Vp = rg->Vp[b] + (int64_t)cam * 21 * P;
+  double* gp = rg->gp[b] + (int64_t)cam * 6 * P;
+  double* Wp = rg->Wp[b] + (int64_t)cam * (NI + 6) * 6 * P;
   for (int64_t slot = 0; slot < S; ++slot) {
-    const int idx = slot_pose[slot];
+    const int idx = k.slot_pose[slot];
     if (idx < 0) continue;
     double pp[6], A[36], B[36], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
-    for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
-    for (int i = 0; i < 21; ++i) Vl[i] = Vb[i * S + slot];
-    for (int i = 0; i < NI * 6; ++i) Wl[i] = Wb[i * S + slot];
-    for (int i = 0; i < 6; ++i) gl[i] = gb[i * S + slot];
-    rig_chain(pp, ext, A, B);
+    for (int c = 0; c < 6; ++c) pp[c] = rg->rig_pose[b][c * P + idx];
+    for (int i = 0; i < 21; ++i) Vl[i] = k.V[i * S + slot];
+    for (int i = 0; i < NI * 6; ++i) Wl[i] = k.W[i * S + slot];
+    for (int i = 0; i < 6; ++i) gl[i] = k.g[i * S + slot];
+    rig_chain(pp, rg->ext[b] + cam * 6, A, B);
     rig_assemble_view<NI>(Vl, Wl, gl, A, B, oV, og, oW, acc);
     for (int i = 0; i < 21; ++i) Vp[i * P + idx] = oV[i];
     for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
     for (int i = 0; i < (NI + 6) * 6; ++i) Wp[i * P + idx] = oW[i];
   }
-  for (int i = 0; i < NACC; ++i) rec[i] = acc[i];
+  for (int i = 0; i < NACC; ++i) rec_ext[i] = acc[i];
 }
 
 template <int G>
-void rig_pose_schur(int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp, double lam, double* Y,
+void rig_pose_schur(int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp, double lam, double* Yt,
                     double* z) {
-  const int64_t ld = (int64_t)n_cams * G;
   for (int64_t p = 0; p < P; ++p) {
     double U[21], g[6];
     const bool ok = rig_pose_factor<G>(n_cams, Vp, gp, P, p, lam, U, g);
     if (ok) chol6_fwd(U, g);
-    for (int k = 0; k < 6; ++k) z[p * 6 + k] = ok ? g[k] : 0.0;
-    for (int c = 0; c < n_cams; ++c)
-      for (int a = 0; a < G; ++a) {
-        double y[6];
-        for (int k = 0; k < 6; ++k) y[k] = Wp[(((int64_t)c * G + a) * 6 + k) * P + p];
-        if (ok) chol6_fwd(U, y);
-        for (int k = 0; k < 6; ++k) Y[(p * 6 + k) * ld + c * G + a] = ok ? y[k] : 0.0;
-      }
+    for (int k = 0; k < 6; ++k) z[k * P + p] = ok ? g[k] : 0.0;
+    for (int v = 0; v < n_cams * G; ++v) {
+      double y[6];
+      for (int k = 0; k < 6; ++k) y[k] = Wp[((int64_t)v * 6 + k) * P + p];
+      if (ok) chol6_fwd(U, y);
+      for (int k = 0; k < 6; ++k) Yt[((int64_t)v * 6 + k) * P + p] = ok ? y[k] : 0.0;
+    }
   }
 }
 
@@ -390,52 +400,67 @@ int camcal_solve_reduced(int model, const double* glob, const double* schur, con
   reduced_solve(ni, glob, schur, mask, lam, scale, intr_in, intr_out, dK, stats, ws);
   return 0;
 }
-int camcal_rig_compose(const camcal_tiles* t, const int32_t* slot_pose, const double* rig_pose, int64_t P,
-                       const double* ext, double* pose_out, void*) {
-  const int64_t S = t->n_slots;
-  for (int64_t slot = 0; slot < S; ++slot) {
-    double out[6] = {0, 0, 0, 0, 0, 1};
-    const int idx = slot_pose[slot];
-    if (idx >= 0) {
-      double pp[6];
-      for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
-      rig_compose(pp, ext, out);
+int64_t camcal_rig_rec_len(int model, int n_cams) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0 || n_cams < 1 || n_cams > CAMCAL_RIG_MAX_CAMS) return CAMCAL_E_BADARG;
+  return RigLayout(ni, n_cams).total;
+}
+int64_t camcal_rig_scratch_len(int, int, const int32_t*, int64_t) { return 16 * 13 + 64; }
+int camcal_rig_evaluate(const camcal_rig* rg, int b, void*) {
+  const int ni = camcal_n_intr(rg->model);
+  const RigLayout L(ni, rg->n_cams);
+  double cost = 0.0;
+  for (int c = 0; c < rg->n_cams; ++c) {
+    double* glob = rg->rec[b] + c * L.per;
+    if (rg->model == 0) {
+      double red[IntrAcc<PINHOLE>::NR];
+      rig_eval_cam<PINHOLE>(rg, b, c, red);
+      IntrAcc<PINHOLE>::expand(red, glob);
+      rig_assemble_cam<9>(rg, b, c, glob + L.NV);
+    } else {
+      double red[IntrAcc<FISHEYE>::NR];
+      rig_eval_cam<FISHEYE>(rg, b, c, red);
+      IntrAcc<FISHEYE>::expand(red, glob);
+      rig_assemble_cam<8>(rg, b, c, glob + L.NV);
     }
-    for (int c = 0; c < 6; ++c) pose_out[c * S + slot] = out[c];
+    cost += glob[L.NV - 1];
+  }
+  rg->rec[b][L.o_cost] = cost;
+  return 0;
+}
+int camcal_rig_eliminate(const camcal_rig* rg, int b, double lam, void*) {
+  const int ni = camcal_n_intr(rg->model);
+  const RigLayout L(ni, rg->n_cams);
+  const int64_t P = rg->P;
+  if (ni == 9) rig_pose_schur<15>(rg->n_cams, P, rg->Vp[b], rg->gp[b], rg->Wp[b], lam, rg->Yt, rg->z);
+  else rig_pose_schur<14>(rg->n_cams, P, rg->Vp[b], rg->gp[b], rg->Wp[b], lam, rg->Yt, rg->z);
+  double* Cm = rg->rec[b] + L.o_C;
+  double* d = rg->rec[b] + L.o_d;
+  const int n = L.n;
+  for (int i = 0; i < n; ++i) {
+    for (int j = i; j < n; ++j) {
+      double s = 0.0;
+      for (int64_t r = 0; r < 6 * P; ++r) s += rg->Yt[(int64_t)i * 6 * P + r] * rg->Yt[(int64_t)j * 6 * P + r];
+      Cm[i * n + j] = s;
+      Cm[j * n + i] = s;
+    }
+    double s = 0.0;
+    for (int64_t r = 0; r < 6 * P; ++r) s += rg->Yt[(int64_t)i * 6 * P + r] * rg->z[r];
+    d[i] = s;
   }
   return 0;
 }
-int camcal_rig_local_blocks(int model, const camcal_tiles* t, const double* intr, const double* pose, double* V,
-                            double* W, double* g, double* glob, double*, void*) {
-  if (model == 0) rig_local_blocks<PINHOLE>(t, intr, pose, V, W, g, glob);
-  else rig_local_blocks<FISHEYE>(t, intr, pose, V, W, g, glob);
-  return 0;
-}
-int camcal_rig_assemble(int model, const camcal_tiles* t, const int32_t* slot_pose, const double* rig_pose, int64_t P,
-                        const double* ext, const double* V, const double* W, const double* g, double* Vp, double* gp,
-                        double* Wp, double* rec_ext, double*, void*) {
-  if (model == 0) rig_assemble<9>(t, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, rec_ext);
-  else rig_assemble<8>(t, slot_pose, rig_pose, P, ext, V, W, g, Vp, gp, Wp, rec_ext);
-  return 0;
-}
-int camcal_rig_pose_schur(int model, int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp,
-                          double lam, double* Y, double* z, void*) {
-  if (model == 0) rig_pose_schur<15>(n_cams, P, Vp, gp, Wp, lam, Y, z);
-  else rig_pose_schur<14>(n_cams, P, Vp, gp, Wp, lam, Y, z);
-  return 0;
-}
-int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uint8_t* mask_host, double lam,
-                             const double* intr_in, const double* ext_in, double* intr_out, double* ext_out,
-                             double* dG, double* stats, void*) {
-  const int ni = camcal_n_intr(model);
+int camcal_rig_solve(const camcal_rig* rg, int b, const uint8_t* mask_host, double lam, int out, void*) {
+  const int ni = camcal_n_intr(rg->model);
   if (ni < 0) return ni;
-  const int n = n_cams * (ni + 6);
-  if (n > RIG_MAXN) return CAMCAL_E_BADARG;
+  const RigLayout L(ni, rg->n_cams);
+  const int n = L.n;
+  if (n > RIG_MAXN - 1) return CAMCAL_E_BADARG;
   unsigned long long mask = 0;
   for (int i = 0; i < n; ++i) if (mask_host[i]) mask |= 1ull << i;
-  static RigSolveWs w;
+  static thread_local RigSolveWs w;
   const int nl = 64;
-  for (int l = 0; l < nl; ++l) rig_solve_build(l, nl, ni, n_cams, rec, mask, lam, w);
+  for (int l = 0; l < nl; ++l) rig_solve_build(l, nl, ni, rg->n_cams, rg->rec[b], mask, lam, w);
   for (int l = 0; l < nl; ++l) rig_solve_scale(l, nl, n, w);
   for (int k = 0; k < n; ++k) {
     for (int l = 0; l < nl; ++l) rig_solve_chol_col(l, nl, n, k, w);
@@ -443,13 +468,15 @@ int camcal_rig_solve_reduced(int model, int n_cams, const double* rec, const uin
     for (int l = 0; l < nl; ++l) rig_solve_chol_update(l, nl, n, k, w);
   }
   rig_solve_substitute(n, w);
-  rig_solve_finish(ni, n_cams, mask, w, intr_in, ext_in, intr_out, ext_out, dG, stats);
+  rig_solve_finish(ni, rg->n_cams, mask, w, rg->intr[b], rg->ext[b], rg->intr[out], rg->ext[out], rg->dG,
+                   rg->rec[out] + L.o_gstats);
   return 0;
 }
-int camcal_rig_backsub(int model, int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp,
-                       double lam, const double* dG, const double* pin, double* pout, double* norms, double*, void*) {
-  if (model == 0) rig_backsub<15>(n_cams, P, Vp, gp, Wp, lam, dG, pin, pout, norms);
-  else rig_backsub<14>(n_cams, P, Vp, gp, Wp, lam, dG, pin, pout, norms);
+int camcal_rig_backsub(const camcal_rig* rg, int b, double lam, int out, void*) {
+  const int ni = camcal_n_intr(rg->model);
+  const RigLayout L(ni, rg->n_cams);
+  if (ni == 9) rig_backsub<15>(rg->n_cams, rg->P, rg->Vp[b], rg->gp[b], rg->Wp[b], lam, rg->dG, rg->rig_pose[b], rg->rig_pose[out], rg->rec[out] + L.o_norms);
+  else rig_backsub<14>(rg->n_cams, rg->P, rg->Vp[b], rg->gp[b], rg->Wp[b], lam, rg->dG, rg->rig_pose[b], rg->rig_pose[out], rg->rec[out] + L.o_norms);
   return 0;
 }
 int camcal_project_points(int model, int64_t n, const double* xyz, const double* pose6, const double* intr,
@@ -563,4 +590,60 @@ int camcal_copy_doubles(double* dst, const double* src, int n, void*) {
   return 0;
 }
 }  // namespace
+namespace {
+int rig_pair_sums(const camcal_rig* rg, double** sums_dev_out, void*) {
+  const int nC = rg->n_cams;
+  double* sums = rg->scratch;
+  for (int i = 0; i < nC * nC * 13; ++i) sums[i] = 0.0;
+  for (int c = 0; c < nC; ++c) {
+    const camcal_rig_cam& k = rg->cam[c];
+    if (!k.pose_slot || !k.pose) return CAMCAL_E_BADARG;
+    for (int64_t p = 0; p < rg->P; ++p) k.pose_slot[p] = -1;
+    for (int64_t s = 0; s < k.tiles.n_slots; ++s)
+      if (k.slot_pose[s] >= 0) k.pose_slot[k.slot_pose[s]] = (int32_t)s;
+  }
+  for (int c = 0; c < nC; ++c)
+    for (int k = 0; k < nC; ++k) {
+      if (c == k) continue;
+      const int64_t Sc = rg->cam[c].tiles.n_slots, Sk = rg->cam[k].tiles.n_slots;
+      double* acc = sums + (c * nC + k) * 13;
+      for (int64_t p = 0; p < rg->P; ++p) {
+        const int sc = rg->cam[c].pose_slot[p], sk = rg->cam[k].pose_slot[p];
+        if (sc < 0 || sk < 0) continue;
+        double qc[6], qk[6], o[12];
+        for (int i = 0; i < 6; ++i) { qc[i] = rg->cam[c].pose[i * Sc + sc]; qk[i] = rg->cam[k].pose[i * Sk + sk]; }
+        rig_pair_terms(qc, qk, o);
+        for (int i = 0; i < 12; ++i) acc[i] += o[i];
+        acc[12] += 1.0;
+      }
+    }
+  *sums_dev_out = sums;
+  return 0;
+}
+int rig_init_poses(const camcal_rig* rg, void*) {
+  for (int64_t p = 0; p < rg->P; ++p) {
+    double out[6] = {0, 0, 0, 0, 0, 1};
+    for (int c = 0; c < rg->n_cams; ++c) {
+      const int s = rg->cam[c].pose_slot[p];
+      if (s < 0) continue;
+      const int64_t S = rg->cam[c].tiles.n_slots;
+      double q[6];
+      for (int i = 0; i < 6; ++i) q[i] = rg->cam[c].pose[i * S + s];
+      rig_pose_from_cam(q, rg->ext[0] + c * 6, out);
+      break;
+    }
+    for (int i = 0; i < 6; ++i) rg->rig_pose[0][i * rg->P + p] = out[i];
+  }
+  return 0;
+}
+int camcal_read_sync(double* dst_host, const double* src, int n, void*) {
+  std::memcpy(dst_host, src, (size_t)n * sizeof(double));
+  return 0;
+}
+int camcal_write_sync(double* dst, const double* src_host, int n, void*) {
+  std::memcpy(dst, src_host, (size_t)n * sizeof(double));
+  return 0;
+}
+}  // namespace
 #include "../../cameracalibration_amd/csrc/camcal_driver.h"
+#include "../../cameracalibration_amd/csrc/camcal_rig_driver.h"

@@ -262,3 +262,22 @@ def test_two_rank_rig_equals_single_rank(emu, tmp_path):
     rv = np.concatenate([p["rv"] for p in parts])
     tv = np.concatenate([p["tv"] for p in parts])
     assert np.allclose(rv, np.hstack(ref[4]).T, atol=1e-8) and np.allclose(tv, np.hstack(ref[5]).T, atol=1e-6)
+
+
+def test_library_sequenced_rig_loop_equals_the_python_loop(emu):
+    """camcal_rig_lm (default) against the same control flow sequenced by rig.lm_rig (chosen by asking
+    for the iteration log): identical stage calls, identical results."""
+    R = small_rig()
+    objs, imgs = R.as_lists()
+    Ks, Ds = R.guess_matrices()
+    res = []
+    for info in ({}, {"log": True}):
+        out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _lib_override=emu,
+                                _device_override=CPU, _info=info)
+        res.append((out, info))
+    (a, ia), (b, ib) = res
+    assert ia["log"] is None and len(ib["log"]) == ib["iters"] == ia["iters"]
+    assert a[0] == b[0]
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(np.hstack(a[4]), np.hstack(b[4]))

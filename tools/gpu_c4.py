@@ -8,13 +8,24 @@ dev = torch.device("cuda:0")
 R = synth.config("C4", device=dev)
 cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c]) for c in range(4)]
 Ks, Ds = R.guess_matrices()
-info = {}
+info = {"log": True}
 t0 = time.perf_counter()
 out = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 40, 1e-7), cams=cams, n_poses=R.n_poses, _info=info)
 torch.cuda.synchronize()
 print("time", time.perf_counter() - t0, "rms", out[0])
 for l in info["log"]:
     print(l)
+from cameracalibration_amd.engine import Engine
+for crit, lpv in (((3, 30, 1e-7), 0), ((3, 100, 1e-7), 0), ((3, 100, 1e-7), 1)):
+    Engine.LANES_PER_VIEW = lpv
+    ts = []
+    for _ in range(4):
+        i2 = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        o2 = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=crit, cams=cams, n_poses=R.n_poses, _info=i2)
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+    print("library loop", crit, "lanes/view", lpv, "ms", [round(t, 2) for t in ts], "iters", i2["iters"], "rms", o2[0])
+Engine.LANES_PER_VIEW = 0
 E = info["engine"]
 intr, ext, poses = E.get_params(0)
 d = np.abs(poses - R.poses_true).max(axis=1)
