@@ -479,6 +479,7 @@ __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const do
   double I[NI], p[6];
   load_intr<NI>(intr, I);
   load_pose(pose, S, slot, p);
+  canonical_rvec(p);
   int it = 0;
   double change = 1.0;
   bool active = tv.n >= 4 && max_iter > 0 && change > tol;
@@ -573,6 +574,7 @@ __global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const d
     double I[NI], q[6];
     load_intr<NI>(intr, I);
     load_pose(pose, S, gv.slot, q);
+    canonical_rvec(q);
     double ch = 1.0;
     bool go = ch > tol;
     while (go) {

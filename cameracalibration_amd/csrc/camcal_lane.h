@@ -253,6 +253,7 @@ CC_HD int lane_pose_refine(const LaneTile& tv, const double* intr, double pose[6
                            double tol) {
   int it = 0;
   double change = 1.0;
+  canonical_rvec(pose);
   while (change > tol && it < max_iter) {
     if (!lane_pose_gn_step<MODEL, PLANAR>(tv, intr, pose, change)) break;
     ++it;

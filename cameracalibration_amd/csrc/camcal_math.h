@@ -241,6 +241,22 @@ CC_HD void rodrigues(const double r[3], double R[9]) {
   R[6] = -A * y + B * x * z;      R[7] = A * x + B * y * z;         R[8] = 1.0 + B * (z * z - th2);
 }
 
+// The Rodrigues vector of the same rotation with |r| <= pi.  cv2 re-derives every pose from
+// a rotation MATRIX at each outer iteration of fisheye::calibrate (InitExtrinsics), so its
+// vectors start every refinement inside that ball; a refinement that is warm-started from
+// the previous vector instead can drift across |r| = pi and would hand back the other
+// representation (r' = r (1 - 2 pi / |r|)) of an identical rotation.
+CC_HD void canonical_rvec(double r[3]) {
+  const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const double pi = 3.141592653589793;
+  if (th2 > pi * pi) {
+    const double th = sqrt(th2);
+    const double k = th - 6.283185307179586 * floor((th + pi) * (1.0 / 6.283185307179586));   // angle in (-pi, pi]
+    const double f = k / th;
+    r[0] *= f; r[1] *= f; r[2] *= f;
+  }
+}
+
 // SO(3) left Jacobian Jl(r) = I + B [r]x + C [r]x^2 (row-major).
 CC_HD void left_jacobian(const double r[3], double J[9]) {
   const double x = r[0], y = r[1], z = r[2];

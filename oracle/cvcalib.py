@@ -367,6 +367,13 @@ def refine_poses_fisheye_batched(views, poses, intr, max_iter=20):
     pose-refine kernel).  Same stopping rule per view; the cond(J) guard is
     evaluated from the eigenvalues of J^T J."""
     out = poses.copy()
+    # a warm start carries the previous Rodrigues vector; cv2 derives each start from a rotation
+    # matrix (InitExtrinsics), i.e. inside |r| <= pi: bring the vector back into that ball first
+    th = np.linalg.norm(out[:, :3], axis=1)
+    far = th > np.pi
+    if far.any():
+        k = th[far] - 2.0 * np.pi * np.floor((th[far] + np.pi) / (2.0 * np.pi))
+        out[far, :3] *= (k / th[far])[:, None]
     iters = np.zeros(views.N, dtype=np.int64)
     for idx, X, uv in views.groups:
         x = out[idx].copy()

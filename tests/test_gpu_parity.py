@@ -365,3 +365,8 @@ def test_multi_rank_loop_through_the_library_communicators(dev):
         from cameracalibration_amd import solver
         solver.destroy_rccl_comms()
         dist.destroy_process_group()
+
+
+def test_cap_hitting_views_match_the_reinitialising_oracle_gpu(dev):
+    from tests.test_hostlogic import cap_hitting_case
+    cap_hitting_case({})
