@@ -98,24 +98,30 @@ def cpu_baseline(seconds_target=12.0):
 
 
 def big_solve(name, n_views, dev, lib):
-    """Whole fisheye solve (pose initialisation + damped Gauss-Newton to the reference's
-    criteria) of a device-resident synthetic set, one run."""
+    """Whole fisheye solve (engine set-up with the layout and the packing, pose initialisation, damped
+    Gauss-Newton to the reference's criteria) of a device-resident synthetic set: second of two runs (the
+    first pays one-time costs -- loading torch's sort kernels, the allocator's first blocks -- and is
+    reported as first_run_ms)."""
     from cameracalibration_amd import solver
     P = synth.config(name, n_views=n_views, device=dev)
     n_obs = P.n_obs
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
-    E.set_intr(0, P.intr_guess())
-    E.pose_init(0, 0)
-    E.pose_refine(0, 0, 20, 1e-10)
-    cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), (3, 1000, 1e-6))
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3
-    intr = E.get_intr(0)
-    return {"ms": ms, "iterations": it, "observations": n_obs, "rms_px": float(np.sqrt(cost / n_obs)),
+    runs = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib)
+        E.set_intr(0, P.intr_guess())
+        E.pose_init(0, 0)
+        E.pose_refine(0, 0, 20, 1e-10)
+        cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), (3, 1000, 1e-6))
+        intr = E.get_intr(0)
+        torch.cuda.synchronize()
+        runs.append((time.perf_counter() - t0) * 1e3)
+        del E
+    return {"ms": runs[1], "first_run_ms": runs[0], "iterations": it, "observations": n_obs,
+            "rms_px": float(np.sqrt(cost / n_obs)),
             "fx_rel_err": float(abs(intr[0] / P.K_true[0] - 1)), "note": "points already on the device; "
-            "includes packing, pose initialisation and every host round trip"}
+            "includes the layout, packing, pose initialisation and every host round trip"}
 
 
 def solve_times(dev, with_cpu=True):

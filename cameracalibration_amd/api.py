@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .engine import Engine
+from .engine import Engine, IncrementalEngine
 from . import solver as _solver
 
 DBL_EPSILON = float(np.finfo(np.float64).eps)
@@ -205,23 +205,8 @@ def _pinhole_mask(flags, nd):
     return mask
 
 
-def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs=None,
-                    tvecs=None, flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON),
-                    *, _lib_override=None, _device_override=None, _comm=None, _info=None):
-    """``cv2.calibrateCamera`` on the MI355X (5-coefficient pinhole model).
-
-    Supported: ``CALIB_USE_INTRINSIC_GUESS`` (required -- the only mode the
-    reference uses) optionally with FIX_FOCAL_LENGTH / FIX_PRINCIPAL_POINT /
-    ZERO_TANGENT_DIST / FIX_TANGENT_DIST / FIX_K1..K3.  Other model flags raise.
-
-    Keyword-only extras (tests, tools): ``_info`` -- a dict that receives
-    ``iters``, ``engine`` and ``log`` (the per-iteration records, collected only
-    when the dict holds ``log=True``: asking for them keeps the loop in
-    solver.py instead of the library); ``_comm`` -- a solver.Comm for a
-    multi-rank solve; ``_lib_override`` / ``_device_override`` -- the tests'
-    CPU lane emulator.
-    """
-    flags = int(flags)
+def _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria):
+    """Argument checks of cv2.calibrateCamera (cvCalibrateCamera2Internal) -> (D, intr0, mask, max_iter, eps)."""
     unsupported = (CALIB_FIX_ASPECT_RATIO | CALIB_RATIONAL_MODEL | CALIB_THIN_PRISM_MODEL |
                    CALIB_TILTED_MODEL)
     if flags & unsupported:
@@ -247,7 +232,6 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
         raise error("Non-zero skew is not supported by the function")
     if abs(K[1, 0]) > 1e-5 or abs(K[2, 0]) > 1e-5 or abs(K[2, 1]) > 1e-5 or abs(K[2, 2] - 1) > 1e-5:
         raise error("The intrinsic matrix must have [fx 0 cx; 0 fy cy; 0 0 1] shape")
-    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
     dist = np.zeros(5)
     dist[:D.size] = D.ravel()
     if flags & CALIB_ZERO_TANGENT_DIST:
@@ -258,13 +242,11 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
         maxc = 1000
     if not ctype & TERM_CRITERIA_EPS:
         eps = DBL_EPSILON
-    _lib_override, dev = _resolve(_lib_override, _device_override)
-    E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=_lib_override)
-    E.set_intr(0, np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], dist]))
-    # cvFindExtrinsicCameraParams2 per view: homography init + iterative refine
-    E.pose_init(0, 0)
-    E.pose_refine(0, 0, 20, 1e-10)
-    comm = _comm or _solver.Comm()
+    return D, np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], dist]), mask, maxc, eps
+
+
+def _solve_pinhole(E, dev, D, mask, maxc, eps, comm, _info, cameraMatrix, distCoeffs):
+    """CvLevMarq from intr[0] / pose[0] of ``E`` (poses initialised) -> the cv2 return tuple."""
     log = [] if (_info is not None and _info.get("log") is True) else None
     try:
         err, iters = _solver.lm_pinhole(E, mask, maxc, eps, comm=comm, log=log)
@@ -289,17 +271,38 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     return rms, _write_back(cameraMatrix, Kout), _write_back(distCoeffs, Dout), rv, tv
 
 
-def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, tvecs=None, flags=0,
-                      criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON),
-                      *, _lib_override=None, _device_override=None, _comm=None, _info=None):
-    """``cv2.fisheye.calibrate`` on the MI355X (Kannala-Brandt, k1..k4).
+def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs=None,
+                    tvecs=None, flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON),
+                    *, _lib_override=None, _device_override=None, _comm=None, _info=None):
+    """``cv2.calibrateCamera`` on the MI355X (5-coefficient pinhole model).
 
-    Supported flag set: ``CALIB_USE_INTRINSIC_GUESS | CALIB_FIX_SKEW`` (both
-    required, as the reference always passes them) with optional
-    ``CALIB_RECOMPUTE_EXTRINSIC``, ``CALIB_FIX_K1..K4``,
-    ``CALIB_FIX_PRINCIPAL_POINT``, ``CALIB_FIX_FOCAL_LENGTH``.
+    Supported: ``CALIB_USE_INTRINSIC_GUESS`` (required -- the only mode the
+    reference uses) optionally with FIX_FOCAL_LENGTH / FIX_PRINCIPAL_POINT /
+    ZERO_TANGENT_DIST / FIX_TANGENT_DIST / FIX_K1..K3.  Other model flags raise.
+    A 4-coefficient ``distCoeffs`` is padded to 5 as cv2 does: k3 is estimated unless
+    ``CALIB_FIX_K3`` and a new 5-element array comes back.
+
+    Keyword-only extras (tests, tools): ``_info`` -- a dict that receives
+    ``iters``, ``engine`` and ``log`` (the per-iteration records, collected only
+    when the dict holds ``log=True``: asking for them keeps the loop in
+    solver.py instead of the library); ``_comm`` -- a solver.Comm for a
+    multi-rank solve; ``_lib_override`` / ``_device_override`` -- the tests'
+    CPU lane emulator.
     """
     flags = int(flags)
+    D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
+    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
+    _lib_override, dev = _resolve(_lib_override, _device_override)
+    E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=_lib_override)
+    E.set_intr(0, intr0)
+    # cvFindExtrinsicCameraParams2 per view: homography init + iterative refine
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    return _solve_pinhole(E, dev, D, mask, maxc, eps, _comm or _solver.Comm(), _info, cameraMatrix, distCoeffs)
+
+
+def _prep_fisheye(K, D, flags):
+    """Argument checks of cv2.fisheye.calibrate -> (intr0, mask)."""
     if flags & FISHEYE_CALIB_CHECK_COND:
         raise error("CALIB_CHECK_COND is not supported")
     if not flags & FISHEYE_CALIB_USE_INTRINSIC_GUESS:
@@ -316,7 +319,6 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
         raise error("D.total() == 4")
     if Kin[0, 1] != 0.0:
         raise error("a non-zero fixed skew is not supported")
-    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
     mask = np.ones(8, dtype=bool)
     if flags & FISHEYE_CALIB_FIX_FOCAL_LENGTH:
         mask[0] = mask[1] = False
@@ -328,13 +330,11 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
         if flags & f:
             mask[4 + j] = False
             k[j] = 0.0
-    _lib_override, dev = _resolve(_lib_override, _device_override)
-    E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=_lib_override)
-    E.set_intr(0, np.concatenate([[Kin[0, 0], Kin[1, 1], Kin[0, 2], Kin[1, 2]], k]))
-    # CalibrateExtrinsics: InitExtrinsics + ComputeExtrinsicRefine per view
-    E.pose_init(0, 0)
-    E.pose_refine(0, 0, 20, 1e-10)
-    comm = _comm or _solver.Comm()
+    return np.concatenate([[Kin[0, 0], Kin[1, 1], Kin[0, 2], Kin[1, 2]], k]), mask
+
+
+def _solve_fisheye(E, dev, mask, flags, criteria, comm, _info, K, D):
+    """cv::fisheye::calibrate's loop from intr[0] / pose[0] of ``E`` -> the cv2 return tuple."""
     log = [] if (_info is not None and _info.get("log") is True) else None
     try:
         cost, iters = _solver.gn_fisheye(E, mask, tuple(criteria),
@@ -354,3 +354,91 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
         _info.update(iters=iters, log=log, engine=E)
     rv, tv = _poses_to_tuples(poses)
     return rms, _write_back(K, Kout), _write_back(D, Dout), rv, tv
+
+
+def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, tvecs=None, flags=0,
+                      criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON),
+                      *, _lib_override=None, _device_override=None, _comm=None, _info=None):
+    """``cv2.fisheye.calibrate`` on the MI355X (Kannala-Brandt, k1..k4).
+
+    Supported flag set: ``CALIB_USE_INTRINSIC_GUESS | CALIB_FIX_SKEW`` (both
+    required, as the reference always passes them) with optional
+    ``CALIB_RECOMPUTE_EXTRINSIC``, ``CALIB_FIX_K1..K4``,
+    ``CALIB_FIX_PRINCIPAL_POINT``, ``CALIB_FIX_FOCAL_LENGTH``.
+    """
+    flags = int(flags)
+    intr0, mask = _prep_fisheye(K, D, flags)
+    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
+    _lib_override, dev = _resolve(_lib_override, _device_override)
+    E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=_lib_override)
+    E.set_intr(0, intr0)
+    # CalibrateExtrinsics: InitExtrinsics + ComputeExtrinsicRefine per view
+    E.pose_init(0, 0)
+    E.pose_refine(0, 0, 20, 1e-10)
+    return _solve_fisheye(E, dev, mask, flags, criteria, _comm or _solver.Comm(), _info, K, D)
+
+
+class CalibrationSession:
+    """The two drop-in calls for a caller whose view lists GROW between calls.
+
+    The reference's capture loops call the solver after every accepted frame with the
+    same lists, one view longer (intrinsicCalib.py:538-564 -> ``Fisheye/Normal.update``
+    :86-94, 100 iterations first, then 10-iteration refinements :129-135).  A session
+    keeps the packed views and the solver state on the device: a call whose lists start
+    with the very arrays of the previous call (checked by identity) uploads and packs only
+    the new views, initialises only their poses and warm-starts the others from the
+    previous result; any other call starts over.  Same signatures, same return tuples and
+    -- to the refinement tolerance -- the same numbers as the one-shot functions
+    (``tests/test_hostlogic.py::test_session_*``)."""
+
+    def __init__(self, model, *, _lib_override=None, _device_override=None):
+        if model not in ("pinhole", "fisheye"):
+            raise error("model must be 'pinhole' or 'fisheye'")
+        self.model = model
+        self._lib_override, self._device_override = _lib_override, _device_override
+        self._E = None
+        self._held = []                 # (object array, image array) of every view on the device
+
+    def _sync(self, objectPoints, imagePoints):
+        """Bring the engine to the given lists; returns the slots of the views added."""
+        lib, dev = _resolve(self._lib_override, self._device_override)
+        nh = len(self._held)
+        same = (self._E is not None and len(objectPoints) >= nh and len(imagePoints) == len(objectPoints) and
+                all(objectPoints[j] is self._held[j][0] and imagePoints[j] is self._held[j][1] for j in range(nh)))
+        if not same:
+            self._E = IncrementalEngine(_lib.PINHOLE if self.model == "pinhole" else _lib.FISHEYE, dev, lib=lib)
+            self._held, nh = [], 0
+        new_o, new_i = list(objectPoints[nh:]), list(imagePoints[nh:])
+        if len(objectPoints) == 0 or len(objectPoints) != len(imagePoints):
+            _gather_views(objectPoints, imagePoints)          # raises like the one-shot call
+        slots = np.zeros(0, dtype=np.int64)
+        if new_o:
+            vp, obj, img = _gather_views(new_o, new_i)
+            slots = self._E.append([obj[vp[j]:vp[j + 1]] for j in range(len(new_o))],
+                                   [img[vp[j]:vp[j + 1]] for j in range(len(new_o))])
+            self._held.extend(zip(new_o, new_i))
+        return self._E, dev, slots
+
+    def calibrateCamera(self, objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs=None, tvecs=None,
+                        flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON), *, _info=None):
+        if self.model != "pinhole":
+            raise error("this session holds a fisheye camera")
+        flags = int(flags)
+        D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
+        E, dev, slots = self._sync(objectPoints, imagePoints)
+        E.set_intr(0, intr0)
+        E.init_new_poses(slots)
+        E.pose_refine(0, 0, 20, 1e-10)
+        return _solve_pinhole(E, dev, D, mask, maxc, eps, _solver.Comm(enabled=False), _info, cameraMatrix, distCoeffs)
+
+    def calibrate(self, objectPoints, imagePoints, image_size, K, D, rvecs=None, tvecs=None, flags=0,
+                  criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON), *, _info=None):
+        if self.model != "fisheye":
+            raise error("this session holds a pinhole camera")
+        flags = int(flags)
+        intr0, mask = _prep_fisheye(K, D, flags)
+        E, dev, slots = self._sync(objectPoints, imagePoints)
+        E.set_intr(0, intr0)
+        E.init_new_poses(slots)
+        E.pose_refine(0, 0, 20, 1e-10)
+        return _solve_fisheye(E, dev, mask, flags, criteria, _solver.Comm(enabled=False), _info, K, D)

@@ -53,11 +53,29 @@ class Engine:
     device : torch device; ``lib``: CamcalLib (default: the HIP build)
     """
 
+    #: from this many views on the layout tables are computed on the device
+    DEVICE_LAYOUT_MIN_VIEWS = 8192
+
+    @property
+    def layout(self):
+        """Host copy of the layout tables (make_layout's dict); made on first use for large sets."""
+        if self._layout is None:
+            T, S = self.tiles.n_tiles, self.S
+            sizes = self.t_tile_nmax.to(torch.int64) * (5 * LANES)
+            self._layout = dict(slot_view=self.t_slot_view.cpu().numpy(), lane_n=self.t_lane_n.cpu().numpy(),
+                                tile_nmax=self.t_tile_nmax.cpu().numpy(), tile_off=self.t_tile_off.cpu().numpy(),
+                                total_floats=int(sizes.sum().item()), n_tiles=T, n_slots=S, n_views=self.n_views)
+        return self._layout
+
+    @layout.setter
+    def layout(self, value):
+        self._layout = value
+
     #: lanes per view of the engines created from now on (camcal_tiles.lanes_per_view: 0 = by size,
     #: 1 / 16 / 64 force a mapping); a plain class default so that tests and tools can pin a mapping
     LANES_PER_VIEW = 0
 
-    def __init__(self, model, view_ptr, obj, img, device, lib=None, lanes_per_view=None):
+    def _setup(self, model, device, lib):
         self.lib = lib if lib is not None else _lib.load()
         self.model = int(model)
         self.device = torch.device(device)
@@ -68,32 +86,57 @@ class Engine:
             raise _lib.CamcalError("unknown camera model")
         self.glob_len = self.lib.camcal_glob_len(self.model)
         self.schur_len = self.lib.camcal_schur_len(self.model)
-        view_ptr = np.ascontiguousarray(torch.as_tensor(view_ptr).cpu().numpy(), dtype=np.int64)
-        n = np.diff(view_ptr)
-        self.n_views = int(n.shape[0])
-        self.n_obs = int(view_ptr[-1])
-        self.n_per_view = n
-        lay = make_layout(n)
-        self.layout = lay
+
+    def __init__(self, model, view_ptr, obj, img, device, lib=None, lanes_per_view=None):
+        self._setup(model, device, lib)
         dev = self.device
-        f64 = dict(dtype=torch.float64, device=dev)
-        # layout tables + CSR offsets: one upload, carved up (int64 tables first: alignment)
-        T, S = lay["n_tiles"], lay["n_slots"]
-        tab = np.concatenate([lay["tile_off"].view(np.int32), view_ptr.view(np.int32), lay["slot_view"],
-                              lay["lane_n"], lay["tile_nmax"]])
-        t_tab = torch.from_numpy(tab).to(dev)
-        o = 0
-        self.t_tile_off = t_tab[o:o + 2 * T].view(torch.int64); o += 2 * T
-        t_vp = t_tab[o:o + 2 * (self.n_views + 1)].view(torch.int64); o += 2 * (self.n_views + 1)
-        self.t_slot_view = t_tab[o:o + S]; o += S
-        self.t_lane_n = t_tab[o:o + S]; o += S
-        self.t_tile_nmax = t_tab[o:o + T]
+        lpv = int(self.LANES_PER_VIEW if lanes_per_view is None else lanes_per_view)
+        n_views = int(len(view_ptr)) - 1
+        if dev.type == "cuda" and n_views >= self.DEVICE_LAYOUT_MIN_VIEWS:
+            # large sets: the sort and the prefix sums of the layout run on the device (the same
+            # tables as make_layout; 1M views cost 10-15 ms in numpy, more than a third of a whole
+            # C5 solve); the host copy of the tables is only made when a caller asks for it
+            t_vp = torch.as_tensor(view_ptr).to(device=dev, dtype=torch.int64)
+            n = t_vp[1:] - t_vp[:-1]
+            self.n_views = n_views
+            T = max((n_views + LANES - 1) // LANES, 1)
+            S = T * LANES
+            order = torch.argsort(n, descending=True, stable=True)
+            self.t_slot_view = torch.full((S,), -1, dtype=torch.int32, device=dev)
+            self.t_slot_view[:n_views] = order.to(torch.int32)
+            self.t_lane_n = torch.zeros(S, dtype=torch.int32, device=dev)
+            self.t_lane_n[:n_views] = n[order].to(torch.int32)
+            self.t_tile_nmax = self.t_lane_n.view(T, LANES).amax(dim=1)
+            sizes = self.t_tile_nmax.to(torch.int64) * (5 * LANES)
+            csum = torch.cumsum(sizes, 0)
+            self.t_tile_off = csum - sizes
+            head = torch.stack([t_vp[-1], csum[-1]]).cpu()          # the one read-back: n_obs, packed floats
+            self.n_obs, total_floats = int(head[0]), int(head[1])
+            self._layout = None
+            lay = dict(n_tiles=T, n_slots=S, total_floats=total_floats)
+        else:
+            view_ptr = np.ascontiguousarray(torch.as_tensor(view_ptr).cpu().numpy(), dtype=np.int64)
+            n = np.diff(view_ptr)
+            self.n_views = int(n.shape[0])
+            self.n_obs = int(view_ptr[-1])
+            lay = make_layout(n)
+            self._layout = lay
+            # layout tables + CSR offsets: one upload, carved up (int64 tables first: alignment)
+            T, S = lay["n_tiles"], lay["n_slots"]
+            tab = np.concatenate([lay["tile_off"].view(np.int32), view_ptr.view(np.int32), lay["slot_view"],
+                                  lay["lane_n"], lay["tile_nmax"]])
+            t_tab = torch.from_numpy(tab).to(dev)
+            o = 0
+            self.t_tile_off = t_tab[o:o + 2 * T].view(torch.int64); o += 2 * T
+            t_vp = t_tab[o:o + 2 * (self.n_views + 1)].view(torch.int64); o += 2 * (self.n_views + 1)
+            self.t_slot_view = t_tab[o:o + S]; o += S
+            self.t_lane_n = t_tab[o:o + S]; o += S
+            self.t_tile_nmax = t_tab[o:o + T]
         self.t_pts = torch.empty(max(lay["total_floats"], 1), dtype=torch.float32, device=dev)   # pack writes all of it
         self.S = S
         self.tiles = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off.data_ptr(),
                                 self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
-                                lay["n_tiles"], S, 0,
-                                int(self.LANES_PER_VIEW if lanes_per_view is None else lanes_per_view))
+                                lay["n_tiles"], S, 0, lpv)
         # pack on the device
         if isinstance(obj, np.ndarray):                     # host arrays: no device round trip for the flag
             planar = not np.asarray(obj).reshape(-1, 3)[:, 2].any()
@@ -108,7 +151,12 @@ class Engine:
         self._call("camcal_pack_tiles", t_obj.data_ptr(), t_img.data_ptr(), t_vp.data_ptr(),
                    self.t_slot_view.data_ptr(), C.byref(self.tiles), self.t_pts.data_ptr(), self._stream())
         del t_obj, t_img, t_vp        # stream-ordered: the allocator reuses them only behind the pack
-        # solver buffers: one zeroed allocation, carved up (every piece a multiple of 8 bytes)
+        self._alloc_solver_buffers(S, lay["n_tiles"])
+
+    def _alloc_solver_buffers(self, S, n_tiles):
+        """Solver state for S slots: one zeroed allocation, carved up (every piece a multiple of 8 bytes)."""
+        dev = self.device
+        f64 = dict(dtype=torch.float64, device=dev)
         NI = self.NI
         sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
                      W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, norms=2, dK=16,
@@ -137,7 +185,7 @@ class Engine:
         self.norms = part["norms"]
         self.view_cost = part["view_cost"]
         # partial sums: every entry a launch reads was written by that launch
-        self.scratch = torch.empty(int(self.lib.camcal_scratch_len(self.model, lay["n_tiles"])), **f64)
+        self.scratch = torch.empty(int(self.lib.camcal_scratch_len(self.model, n_tiles)), **f64)
         ints = torch.zeros(2 * S, dtype=torch.int32, device=dev)
         self.status, self.iters = ints[:S], ints[S:]
 
@@ -337,3 +385,134 @@ class Engine:
                    self.W.data_ptr(), self.g.data_ptr(), self.glob[0].data_ptr(),
                    self.schur.data_ptr(), self.scratch.data_ptr(), self._stream(), C.byref(ms))
         return float(ms.value)
+
+
+class IncrementalEngine(Engine):
+    """Engine for the growing-list caller (the reference calls the solver once per captured
+    frame with a longer list, intrinsicCalib.py:538-564 -> :86-94,129-135): views are
+    APPENDED, only the tiles they touch are packed, the solver buffers and the poses of the
+    views already held stay on the device (the next solve warm-starts from them).
+
+    Views keep their arrival order (slot = view index): tile t holds views 64 t .. 64 t + 63,
+    only the last tile is partly filled and only it can grow, its rows being the end of the
+    packed buffer.  Capacity (tiles, packed floats) doubles when exceeded; a rebuild re-packs
+    from the host copies and carries the poses over."""
+
+    def __init__(self, model, device, lib=None, capacity_views=256, lanes_per_view=None):
+        self._setup(model, device, lib)
+        self._lpv = int(self.LANES_PER_VIEW if lanes_per_view is None else lanes_per_view)
+        self._views = []                       # host copies (obj (n,3) f32, img (n,2) f32)
+        self._alloc(max(int(capacity_views), LANES), 0)
+
+    # -- storage -----------------------------------------------------------------
+    def _alloc(self, capacity_views, capacity_floats):
+        T = (capacity_views + LANES - 1) // LANES
+        S = T * LANES
+        dev = self.device
+        self.S, self._T = S, T
+        self.n_views, self.n_obs = 0, 0
+        self._lane_n = np.zeros(S, dtype=np.int32)
+        self._tile_nmax = np.zeros(T, dtype=np.int32)
+        self._tile_off = np.zeros(T, dtype=np.int64)
+        self._floats = 0                       # packed floats in use
+        self._cap_floats = max(int(capacity_floats), 5 * LANES * 128)
+        self.t_pts = torch.zeros(self._cap_floats, dtype=torch.float32, device=dev)
+        self.t_tile_off = torch.zeros(T, dtype=torch.int64, device=dev)
+        self.t_tile_nmax = torch.zeros(T, dtype=torch.int32, device=dev)
+        self.t_lane_n = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.tiles = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off.data_ptr(), self.t_tile_nmax.data_ptr(),
+                                self.t_lane_n.data_ptr(), T, S, 1, self._lpv)
+        sv = np.full(S, -1, dtype=np.int32)
+        self.layout = dict(slot_view=sv, lane_n=self._lane_n, tile_nmax=self._tile_nmax, tile_off=self._tile_off,
+                           n_tiles=T, n_slots=S, n_views=0, total_floats=0)
+        self._alloc_solver_buffers(S, T)
+
+    def _grow(self, need_views, need_floats):
+        """Double the capacity, re-pack every view from the host copies, keep the poses."""
+        views, old_n = self._views, self.n_views
+        old_pose = self.pose[0][:, :old_n].clone() if old_n else None
+        old_intr = self.intr[0].clone()
+        cap_v = self.S
+        while cap_v < need_views:
+            cap_v *= 2
+        cap_f = self._cap_floats
+        while cap_f < need_floats:
+            cap_f *= 2
+        self._views = []
+        self._alloc(cap_v, cap_f)
+        if views:
+            self.append([v[0] for v in views], [v[1] for v in views])
+        if old_pose is not None:
+            self.pose[0][:, :old_n] = old_pose
+        self.intr[0].copy_(old_intr)
+
+    # -- growing -------------------------------------------------------------------
+    def append(self, objs, imgs):
+        """Add views (lists of (n,3) / (n,2) float32 arrays, Z = 0).  Returns the slots they took."""
+        k = len(objs)
+        if k == 0:
+            return np.zeros(0, dtype=np.int64)
+        counts = np.array([o.shape[0] for o in objs], dtype=np.int32)
+        n0, n1 = self.n_views, self.n_views + k
+        T0 = n0 // LANES                                     # first tile touched
+        T1 = (n1 + LANES - 1) // LANES                       # one past the last tile in use
+        if n1 > self.S:
+            need_f = self._floats + int(counts.astype(np.int64).max()) * 5 * LANES * ((k + LANES - 1) // LANES + 1)
+            self._grow(n1, need_f)
+            return self.append(objs, imgs)
+        # sizes after the append: the touched tiles are re-laid out from tile T0 on
+        lane_n = self._lane_n.copy()
+        lane_n[n0:n1] = counts
+        off0 = int(self._tile_off[T0])
+        nmax = lane_n[T0 * LANES:T1 * LANES].reshape(-1, LANES).max(axis=1).astype(np.int32)
+        sizes = nmax.astype(np.int64) * (5 * LANES)
+        end = off0 + int(sizes.sum())
+        if end > self._cap_floats:
+            self._grow(n1, end)
+            return self.append(objs, imgs)
+        offs = off0 + np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        self._lane_n = lane_n
+        self._tile_nmax[T0:T1] = nmax
+        self._tile_off[T0:T1] = offs
+        if T1 < self._T:
+            self._tile_off[T1:] = end                        # empty tiles point at valid memory
+        self._floats = end
+        for o, i in zip(objs, imgs):
+            self._views.append((o, i))
+        self.n_views = n1
+        self.n_obs += int(counts.sum())
+        self.layout["slot_view"][n0:n1] = np.arange(n0, n1, dtype=np.int32)
+        self.layout.update(lane_n=self._lane_n, n_views=n1, total_floats=end)
+        # device tables of the touched range
+        dev = self.device
+        self.t_lane_n[T0 * LANES:T1 * LANES].copy_(torch.from_numpy(lane_n[T0 * LANES:T1 * LANES]).to(dev))
+        self.t_tile_nmax[T0:T1].copy_(torch.from_numpy(self._tile_nmax[T0:T1]).to(dev))
+        self.t_tile_off[T0:].copy_(torch.from_numpy(self._tile_off[T0:]).to(dev))
+        # pack the touched tiles (the partly filled one again in full: its rows may have grown)
+        v0 = T0 * LANES
+        sub = self._views[v0:n1]
+        vp = np.zeros(len(sub) + 1, dtype=np.int64)
+        vp[1:] = np.cumsum([o.shape[0] for o, _ in sub])
+        t_obj = torch.from_numpy(np.concatenate([o for o, _ in sub])).to(dev)
+        t_img = torch.from_numpy(np.concatenate([i for _, i in sub])).to(dev)
+        t_vp = torch.from_numpy(vp).to(dev)
+        nsub = (T1 - T0) * LANES
+        sv = np.full(nsub, -1, dtype=np.int32)
+        sv[:len(sub)] = np.arange(len(sub), dtype=np.int32)
+        t_sv = torch.from_numpy(sv).to(dev)
+        part = _lib.Tiles(self.t_pts.data_ptr(), self.t_tile_off[T0:].data_ptr(), self.t_tile_nmax[T0:].data_ptr(),
+                          self.t_lane_n[T0 * LANES:].data_ptr(), T1 - T0, nsub, 1, self._lpv)
+        self._call("camcal_pack_tiles", t_obj.data_ptr(), t_img.data_ptr(), t_vp.data_ptr(), t_sv.data_ptr(),
+                   C.byref(part), self.t_pts.data_ptr(), self._stream())
+        return np.arange(n0, n1, dtype=np.int64)
+
+    def init_new_poses(self, slots, intr_idx=0):
+        """Pose initialisation of the appended views only: the launch covers every slot (small sets: tens of
+        microseconds) into the spare pose buffer, the new columns are copied over; the views already held keep
+        their poses as the warm start of the next refinement."""
+        if len(slots) == 0:
+            return
+        self._call("camcal_pose_init", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[1].data_ptr(), self.status.data_ptr(), self._stream())
+        lo, hi = int(slots[0]), int(slots[-1]) + 1
+        self.pose[0][:, lo:hi] = self.pose[1][:, lo:hi]

@@ -45,11 +45,13 @@ NORMAL_INIT_D = ((-0.404256259818931,), (0.21922420928359876,), (-0.000161818024
                  (-7.126641144546051e-05,), (-0.06924570764420157,))
 
 
-def _solve(kind, obj, img, frame_size, K, D, max_iter):
+def _solve(kind, obj, img, frame_size, K, D, max_iter, session=None):
+    """The reference's solver call; ``session``: an api.CalibrationSession of a growing-list caller."""
     if kind == "fisheye":
-        return _fe.calibrate(obj, img, frame_size, K, D, flags=_FE_FLAGS, criteria=(_CRIT, max_iter, 1e-6))
-    return api.calibrateCamera(obj, img, frame_size, K, D, flags=api.CALIB_USE_INTRINSIC_GUESS,
-                               criteria=(_CRIT, max_iter, 1e-6))
+        fn = session.calibrate if session is not None else _fe.calibrate
+        return fn(obj, img, frame_size, K, D, flags=_FE_FLAGS, criteria=(_CRIT, max_iter, 1e-6))
+    fn = session.calibrateCamera if session is not None else api.calibrateCamera
+    return fn(obj, img, frame_size, K, D, flags=api.CALIB_USE_INTRINSIC_GUESS, criteria=(_CRIT, max_iter, 1e-6))
 
 
 def _within_gates(K, D, K_nominal, D_nominal, rel):
@@ -211,6 +213,9 @@ class _Incremental:
         self.board = []
         self.frame_width, self.frame_height = frame_width, frame_height
         self.focal_scale, self.size_scale = focal_scale, size_scale
+        # update() is called after every accepted frame with the same lists, one view longer
+        # (intrinsicCalib.py:538-564): the session keeps the views already packed on the device
+        self._session = api.CalibrationSession(self._kind)
 
     def update(self, corners, frame_size):
         if not self.inited:
@@ -227,7 +232,7 @@ class _Incremental:
         data.camera_mat = self.init_camera_mat           # not copied: the solver writes into the nominal arrays
         data.dist_coeff = self.init_dist_coeff
         data.ok, data.camera_mat, data.dist_coeff, data.rvecs, data.tvecs = _solve(
-            self._kind, board, corners, frame_size, data.camera_mat, data.dist_coeff, 100)
+            self._kind, board, corners, frame_size, data.camera_mat, data.dist_coeff, 100, self._session)
         if not _within_gates(data.camera_mat, data.dist_coeff, self.init_camera_mat, self.init_dist_coeff, 0.15):
             data.check = False
         data.ok = data.ok and data.check and points.checkRange(data.camera_mat) and points.checkRange(data.dist_coeff)
@@ -235,7 +240,7 @@ class _Incremental:
     def _update_refine(self, board, corners, frame_size):
         data = self.data
         data.ok, data.camera_mat, data.dist_coeff, data.rvecs, data.tvecs = _solve(
-            self._kind, board, corners, frame_size, data.camera_mat, data.dist_coeff, 10)
+            self._kind, board, corners, frame_size, data.camera_mat, data.dist_coeff, 10, self._session)
         data.ok = data.ok and points.checkRange(data.camera_mat) and points.checkRange(data.dist_coeff)
 
     def _calc_reproj_err(self, corners):

@@ -1,6 +1,7 @@
 """Shared bodies of the point-level parity tests (N1-N4): run with the CPU lane
 emulator in the CPU tier and with the HIP library in the GPU tier."""
 import numpy as np
+import pytest
 
 import cameracalibration_amd as cc
 from cameracalibration_amd import synth, wrappers
@@ -331,3 +332,37 @@ def case_on_axis_point():
 
 
 ALL.append(case_on_axis_point)
+
+
+def case_session_growing_lists():
+    """cc.CalibrationSession (the growing-list caller of intrinsicCalib.py:538-564: one more view per call, 100
+    iterations first, 10-iteration refinements after) against fresh one-shot calls on the same lists: the views
+    already packed stay on the device, old poses warm-start the refinement, and every call returns what a fresh
+    call returns to 1e-9; lists that are not an extension of the previous ones start the session over."""
+    for model, cfg, fl in (("fisheye", "C2", FE), ("pinhole", "C1", 1)):
+        P = synth.config(cfg, n_views=70)                      # crosses a tile boundary and the first capacity
+        objs, imgs = P.as_lists()
+        ses = cc.CalibrationSession(model)
+        one = cc.fisheye.calibrate if model == "fisheye" else cc.calibrateCamera
+        inc = ses.calibrate if model == "fisheye" else ses.calibrateCamera
+        K, D = P.K_guess.copy(), P.D_guess.copy()
+        Kf, Df = P.K_guess.copy(), P.D_guess.copy()
+        for step, n in enumerate((6, 7, 8, 30, 64, 65, 70)):
+            crit = (3, 100 if step == 0 else 10, 1e-6)
+            a = inc(objs[:n], imgs[:n], P.image_size, K, D, flags=fl, criteria=crit)
+            b = one(objs[:n], imgs[:n], P.image_size, Kf, Df, flags=fl, criteria=crit)
+            assert a[1] is K and ses._E.n_views == n
+            assert abs(a[0] - b[0]) < 1e-9, (model, n, a[0], b[0])
+            assert np.allclose(a[1], b[1], rtol=1e-9) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-10)
+            assert np.allclose(np.hstack(a[3]), np.hstack(b[3]), atol=1e-7)
+            assert np.allclose(np.hstack(a[4]), np.hstack(b[4]), atol=1e-5)
+        # another list (here: the views in another order) is not an extension: the session starts over
+        E_before = ses._E
+        a = inc(objs[10:20], imgs[10:20], P.image_size, K, D, flags=fl, criteria=(3, 10, 1e-6))
+        b = one(objs[10:20], imgs[10:20], P.image_size, Kf, Df, flags=fl, criteria=(3, 10, 1e-6))
+        assert ses._E is not E_before and ses._E.n_views == 10 and abs(a[0] - b[0]) < 1e-9
+        with pytest.raises(cc.error):
+            inc(objs[:3], imgs[:2], P.image_size, K, D, flags=fl, criteria=(3, 10, 1e-6))
+
+
+ALL.append(case_session_growing_lists)

@@ -370,3 +370,24 @@ def test_multi_rank_loop_through_the_library_communicators(dev):
 def test_cap_hitting_views_match_the_reinitialising_oracle_gpu(dev):
     from tests.test_hostlogic import cap_hitting_case
     cap_hitting_case({})
+
+
+def test_device_side_layout_equals_the_host_layout(dev):
+    """Large sets build their slot / tile tables on the device (engine.py); same tables as make_layout /
+    camcal_layout, bit for bit, on a ragged set -- and the packed points and a record built from them agree."""
+    from cameracalibration_amd.engine import make_layout
+    P = synth.config("C3", n_views=20000, device=dev)
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    assert E._layout is None                                   # the device path ran
+    ref = make_layout(np.diff(np.asarray(P.view_ptr)))
+    lay = E.layout
+    for k in ("slot_view", "lane_n", "tile_nmax", "tile_off"):
+        assert np.array_equal(lay[k], ref[k]), k
+    assert (lay["total_floats"], lay["n_tiles"], lay["n_slots"]) == (ref["total_floats"], ref["n_tiles"], ref["n_slots"])
+    old = Engine.DEVICE_LAYOUT_MIN_VIEWS
+    Engine.DEVICE_LAYOUT_MIN_VIEWS = 10 ** 9
+    try:
+        F = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    finally:
+        Engine.DEVICE_LAYOUT_MIN_VIEWS = old
+    assert F._layout is not None and torch.equal(E.t_pts, F.t_pts) and E.n_obs == F.n_obs

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Growing-list caller (intrinsicCalib.py:538-564): per-call time of cc.CalibrationSession against
+fresh one-shot calls, one more view per call, 10-iteration refinements (development tool)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import cameracalibration_amd as cc
+from cameracalibration_amd import synth
+FE = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
+for model, cfg, fl in (("fisheye", "C2", FE), ("pinhole", "C1", 1)):
+    P = synth.config(cfg, n_views=80)
+    objs, imgs = P.as_lists()
+    for rep in range(2):
+        ses = cc.CalibrationSession(model)
+        one = cc.fisheye.calibrate if model == "fisheye" else cc.calibrateCamera
+        inc = ses.calibrate if model == "fisheye" else ses.calibrateCamera
+        K, D = P.K_guess.copy(), P.D_guess.copy()
+        Kf, Df = P.K_guess.copy(), P.D_guess.copy()
+        t_inc, t_one = [], []
+        for step, n in enumerate(range(10, 81)):
+            crit = (3, 100 if step == 0 else 10, 1e-6)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            a = inc(objs[:n], imgs[:n], P.image_size, K, D, flags=fl, criteria=crit)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            b = one(objs[:n], imgs[:n], P.image_size, Kf, Df, flags=fl, criteria=crit)
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            t_inc.append((t1 - t0) * 1e3); t_one.append((t2 - t1) * 1e3)
+            assert abs(a[0] - b[0]) < 1e-9
+    print(f"{model}: 70 calls, 10 -> 80 views: session median {np.median(t_inc[1:]):.3f} ms, one-shot median {np.median(t_one[1:]):.3f} ms")
