@@ -22,8 +22,8 @@ oracle:
 	$(MAKE) -C oracle
 
 # pure C-ABI host program (no Python, no torch); run on the GPU box by tests/test_gpu_cabi.py
-examples: examples/cabi_fisheye
-examples/cabi_fisheye: examples/cabi_fisheye.cpp include/camcal.h $(CSRC)/libcamcal.so
+examples: examples/cabi_fisheye examples/cabi_rig
+examples/cabi_%: examples/cabi_%.cpp include/camcal.h $(CSRC)/libcamcal.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 $< -o $@ -L$(CSRC) -lcamcal -Wl,-rpath,'$$ORIGIN/../$(CSRC)'
 
 # issue-rate microbenchmarks behind DESIGN.md section 4 (run on the GPU box: tools/ubench/ubench)
@@ -32,7 +32,7 @@ tools/ubench/ubench: tools/ubench/ubench.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
 
 clean:
-	rm -f tools/ubench/ubench $(CSRC)/libcamcal.so tests/hostemu/libcamcal_hostemu.so examples/cabi_fisheye
+	rm -f tools/ubench/ubench $(CSRC)/libcamcal.so tests/hostemu/libcamcal_hostemu.so examples/cabi_fisheye examples/cabi_rig
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib hostemu oracle examples ubench clean

@@ -16,3 +16,13 @@ def test_c_host_program_calibrates_through_the_abi():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
+
+
+@pytest.mark.gpu
+def test_c_host_program_calibrates_a_rig_through_the_abi():
+    """The multi-camera rig (BASELINE config 4) from include/camcal.h alone: camcal_rig_init + camcal_rig_lm."""
+    exe = os.path.join(ROOT, "examples", "cabi_rig")
+    assert os.path.exists(exe), "run `make examples` (the driver's build() does)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK")
