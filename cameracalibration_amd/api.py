@@ -175,12 +175,12 @@ def _poses_to_tuples(poses):
     return rvecs, tvecs
 
 
-def _raise_degenerate(E, cause=None):
+def _raise_degenerate(E, cause=None, bad=None):
     """cv2 has no usable answer for a view whose points are collinear or coincident (its
     homography / SVD pose start is garbage and the solve returns non-finite values for the
     caller's checkRange); this module raises instead and names the views."""
-    st = E.slots_to_views(E.status)
-    bad = np.flatnonzero(st != 0)
+    if bad is None:
+        bad = np.flatnonzero(E.slots_to_views(E.status) != 0)
     if bad.size:
         raise error("degenerate view(s) %s: the pose initialisation failed (collinear / coincident points); "
                     "remove them" % (bad[:16].tolist(),))
@@ -253,11 +253,10 @@ def _solve_pinhole(E, dev, D, mask, maxc, eps, comm, _info, cameraMatrix, distCo
     except _lib.CamcalNumericError as exc:
         _raise_degenerate(E, exc)
         raise
-    _raise_degenerate(E)
+    intr, poses, bad = E.read_solution()
+    _raise_degenerate(E, bad=bad)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(err / n_total))
-    intr = E.get_intr(0)
-    poses = E.get_poses(0)
     Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])
     if D.size == 5:
         Dout = intr[4:9].reshape(np.asarray(distCoeffs).shape)
@@ -343,11 +342,10 @@ def _solve_fisheye(E, dev, mask, flags, criteria, comm, _info, K, D):
     except _lib.CamcalNumericError as exc:
         _raise_degenerate(E, exc)
         raise
-    _raise_degenerate(E)
+    intr, poses, bad = E.read_solution()
+    _raise_degenerate(E, bad=bad)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(cost / n_total))
-    intr = E.get_intr(0)
-    poses = E.get_poses(0)
     Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])
     Dout = intr[4:8].reshape(np.asarray(D).shape)
     if _info is not None:

@@ -216,9 +216,9 @@ class Engine:
 
     # -- parameters ------------------------------------------------------------
     def set_intr(self, which, values):
-        v = torch.zeros(16, dtype=torch.float64)
-        v[:self.NI] = torch.as_tensor(np.asarray(values, dtype=np.float64)[:self.NI])
-        self.intr[which].copy_(v.to(self.device))
+        v = np.zeros(16)
+        v[:self.NI] = np.asarray(values, dtype=np.float64)[:self.NI]
+        self.intr[which].copy_(torch.from_numpy(v))          # one host-to-device copy
 
     def get_intr(self, which):
         return self.intr[which][:self.NI].cpu().numpy().copy()
@@ -240,6 +240,30 @@ class Engine:
         out = np.empty((self.n_views, 6))
         out[sv[valid]] = p[valid]
         return out
+
+    def read_solution(self):
+        """(intrinsics (NI,), poses (N, 6) in the caller's view order, indices of the views whose pose
+        initialisation failed) of buffer 0 -- for small sets one device-to-host copy instead of three."""
+        S = self.S
+        pool = self._pool
+        head = 32 + 12 * S                     # intr0 | intr1 | pose0 | pose1 at the head of the pool
+        if S <= 8192:
+            h = pool[:head].cpu().numpy()
+            base = pool.data_ptr()
+            io = (self.intr[0].data_ptr() - base) // 8
+            po = (self.pose[0].data_ptr() - base) // 8
+            intr = h[io:io + self.NI].copy()
+            p = h[po:po + 6 * S].reshape(6, S).T
+        else:
+            intr = self.get_intr(0)
+            p = self.pose[0].cpu().numpy().T
+        sv = self.layout["slot_view"]
+        valid = sv >= 0
+        poses = np.empty((self.n_views, 6))
+        poses[sv[valid]] = p[valid]
+        st = self.status.cpu().numpy()
+        bad = np.sort(sv[valid][st[valid] != 0])
+        return intr, poses, bad
 
     def slots_to_views(self, per_slot):
         a = per_slot.cpu().numpy()
