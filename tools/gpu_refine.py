@@ -24,4 +24,6 @@ for k in range(7):
     ms = timed(lambda: E.pose_refine(0, 0, 20, 1e-10))
     it = E.iters.cpu().numpy()
     tile_max = it.reshape(-1, 64).max(axis=1)
-    print("iter %d refine %.2f ms, iters mean %.2f max %d, mean of per-tile max %.2f, hist %s" % (k, ms, it.mean(), it.max(), tile_max.mean(), np.bincount(it)[:12]))
+    tot = locals().get("tot", 0.0) + ms
+    print("iter %d refine %.2f ms, iters mean %.2f (balanced: %.2f ms)" % (k, ms, it.mean(), it.mean() * 0.75))
+print("TOTAL of the 7 re-estimations %.2f ms" % tot)

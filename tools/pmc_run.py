@@ -25,5 +25,9 @@ for _ in range(3):
     E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
 for _ in range(3):
     E.normal_eq(0, 0, 0.0, store_blocks=True, fused=False)
+# pose re-estimation: from the homography initialisation (the first refinement of a solve)
+E.pose_init(0, 0)
+E.pose_refine(0, 0, 20, 1e-10)
+print('refine steps', float(E.iters.double().sum().item()))
 torch.cuda.synchronize()
 print('done')
