@@ -204,21 +204,6 @@ def solve_times(dev, with_cpu=True):
     return out
 
 
-class stdout_to_stderr:
-    """RCCL prints a version banner on stdout when a communicator is created; the contract of this
-    script is ONE JSON line on stdout."""
-
-    def __enter__(self):
-        sys.stdout.flush()
-        self.saved = os.dup(1)
-        os.dup2(2, 1)
-
-    def __exit__(self, *exc):
-        sys.stdout.flush()
-        os.dup2(self.saved, 1)
-        os.close(self.saved)
-
-
 def timed_steps(step, steps, world, dev):
     """EXACTLY `steps` steps between barrier + synchronize on both sides; returns (wall seconds, max
     over ranks; HIP-event milliseconds per step on this rank's stream)."""
@@ -351,6 +336,11 @@ def main():
     ap.add_argument("--no-solves", action="store_true", help="skip the whole-solve wall-clock extras")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: everything else a library may print there (RCCL's version banner at
+    # communicator creation, ...) goes to stderr; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -363,8 +353,7 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = _lib.load()
     from cameracalibration_amd import solver
@@ -383,8 +372,7 @@ def main():
             lo, hi = shard_ranges(np.full(args.views, 88, dtype=np.int64), world)[rank]
             nv_rank = hi - lo
         E, n_obs, n_views = make_engine(lib, nv_rank, dev, seed=5 + rank)
-        with stdout_to_stderr():
-            handle = comm.handle(E)
+        handle = comm.handle(E)
         step = make_step(E, lib, handle)
         for _ in range(prewarm + args.warmup):
             step()
@@ -488,7 +476,8 @@ def main():
             out["solve_wall_clock"] = solve_times(dev, with_cpu=not args.no_cpu_baseline)
             torch.cuda.empty_cache()
             out["kernels"] = kernel_extras(dev, lib)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         solver.destroy_rccl_comms()
         dist.destroy_process_group()

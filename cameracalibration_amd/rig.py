@@ -361,6 +361,8 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
     R.set_params(0, intr0, np.zeros((nC, 6)))
     if _init is None:
         R.init_from_guess(comm)
+        if int(R.status.count_nonzero().item()):
+            raise ValueError("a view is degenerate (collinear / coincident points): its pose initialisation failed")
     else:
         R.set_params(0, intr0, _init[0], _init[1])
     NI, G = R.NI, R.G
