@@ -1161,7 +1161,10 @@ inline int grid_persistent(const camcal_tiles* t) {
 // small planar sets.  The partial records of a grouped launch are one per wavefront
 // (n_tiles * G of them) and must fit the scratch every caller holds (camcal_scratch_len).
 constexpr int GROUP64_MAX_TILES = 32;      // <= 2048 views: one wavefront per view
-constexpr int GROUP16_MAX_TILES = 128;     // <= 8192 views: four views per wavefront
+constexpr int GROUP16_MAX_TILES = 256;     // <= 16384 views: four views per wavefront (measured ahead of one lane per view up to
+                                           // 32768; 256 tiles x 16 = MAX_WAVES partial records is what the scratch layouts hold)
+static_assert(GROUP64_MAX_TILES * 64 <= MAX_WAVES && GROUP16_MAX_TILES * 16 <= MAX_WAVES,
+              "grouped launches write one partial record per wavefront into MAX_WAVES-strided scratch");
 inline int group_lanes(const camcal_tiles* t) {
   const int want = t->lanes_per_view;      // 0: by size
   if (!t->planar || want == 1) return 1;
@@ -1220,7 +1223,8 @@ int camcal_schur_len(int model) {
 }
 int64_t camcal_scratch_len(int model, int n_tiles) {
   (void)model;
-  const int64_t a = (int64_t)MAX_NV * MAX_WAVES, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
+  // persistent / grouped launches: <= MAX_WAVES partial records of <= STATIC_ROWS values; one lane per view: one per tile
+  const int64_t a = (int64_t)STATIC_ROWS * MAX_WAVES, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
   return (a > b ? a : b) + 2 * MAX_NV;   // + the reduced values ahead of their expansion
 }
 
@@ -1820,6 +1824,65 @@ struct camcal_reader {
     return 0;
   }
 };
+
+// Side streams for stages that are independent per camera (camcal_rig_init: the pose
+// initialisation of 4 cameras x 157 tiles each fills a sixth of the device when the cameras
+// run one after another).  fork: the side streams wait for everything queued on `stream`;
+// join: `stream` waits for the side streams.  One set per device, kept until the process
+// ends; the mutex covers one fork or join (a few enqueues), so concurrent callers on a
+// device serialise their side work but stay correct.
+struct SideStreams {
+  hipStream_t s[CAMCAL_RIG_MAX_CAMS - 1] = {};
+  hipEvent_t fork = nullptr, join[CAMCAL_RIG_MAX_CAMS - 1] = {};
+  int dev = -1;
+};
+std::mutex g_side_mu;
+std::vector<SideStreams*> g_side;
+
+int side_streams(SideStreams** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  for (SideStreams* k : g_side)
+    if (k->dev == dev) { *out = k; return 0; }
+  SideStreams* n = new SideStreams();
+  n->dev = dev;
+  hipError_t e = hipEventCreateWithFlags(&n->fork, hipEventDisableTiming);
+  for (int i = 0; i < CAMCAL_RIG_MAX_CAMS - 1 && e == hipSuccess; ++i) {
+    e = hipStreamCreateWithFlags(&n->s[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&n->join[i], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) return (int)e;            // a failed set is not kept (and not freed: the process is in trouble)
+  g_side.push_back(n);
+  *out = n;
+  return 0;
+}
+int camcal_fork_streams(void* stream, int n, void** side_out) {
+  side_out[0] = stream;
+  if (n <= 1) return 0;
+  if (n > CAMCAL_RIG_MAX_CAMS) return CAMCAL_E_BADARG;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStreams* k = nullptr;
+  const int rc = side_streams(&k);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(k->fork, (hipStream_t)stream));
+  for (int i = 1; i < n; ++i) {
+    HIP_TRY(hipStreamWaitEvent(k->s[i - 1], k->fork, 0));
+    side_out[i] = k->s[i - 1];
+  }
+  return 0;
+}
+int camcal_join_streams(void* stream, int n, void** side) {
+  if (n <= 1) return 0;
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  SideStreams* k = nullptr;
+  const int rc = side_streams(&k);
+  if (rc) return rc;
+  for (int i = 1; i < n; ++i) {
+    HIP_TRY(hipEventRecord(k->join[i - 1], (hipStream_t)side[i]));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, k->join[i - 1], 0));
+  }
+  return 0;
+}
 
 int camcal_copy_doubles(double* dst, const double* src, int n, void* stream) {
   HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -25,31 +25,6 @@
 
 namespace camcal {
 
-// C = A^T B (all 6x6 row-major)
-CC_HD void mat6_atb(const double* A, const double* B, double* C) {
-  CC_UNROLL
-  for (int i = 0; i < 6; ++i)
-    CC_UNROLL
-    for (int j = 0; j < 6; ++j) {
-      double s = 0.0;
-      CC_UNROLL
-      for (int k = 0; k < 6; ++k) s = fma(A[k * 6 + i], B[k * 6 + j], s);
-      C[i * 6 + j] = s;
-    }
-}
-// C = A B
-CC_HD void mat6_ab(const double* A, const double* B, double* C) {
-  CC_UNROLL
-  for (int i = 0; i < 6; ++i)
-    CC_UNROLL
-    for (int j = 0; j < 6; ++j) {
-      double s = 0.0;
-      CC_UNROLL
-      for (int k = 0; k < 6; ++k) s = fma(A[i * 6 + k], B[k * 6 + j], s);
-      C[i * 6 + j] = s;
-    }
-}
-
 CC_HD void mat3_mul(const double* A, const double* B, double* C) {
   CC_UNROLL
   for (int i = 0; i < 3; ++i)
@@ -69,79 +44,140 @@ CC_HD void rig_compose(const double pose_p[6], const double ext[6], double out[6
     out[3 + i] = Rc[i * 3] * pose_p[3] + Rc[i * 3 + 1] * pose_p[4] + Rc[i * 3 + 2] * pose_p[5] + ext[3 + i];
 }
 
-// chain matrices A (d xi / d ext) and B (d xi / d pose), 6x6 row-major
-CC_HD void rig_chain(const double pose_p[6], const double ext[6], double A[36], double B[36]) {
-  double Rc[9], Jlp[9], Jlc[9], M1[9];
-  rodrigues(ext, Rc);
+// Chain matrices A (d xi / d ext) and B (d xi / d pose) by their 3x3 blocks (row-major):
+//   A = [ J 0 ]      B = [ M 0 ]      J = Jl(r_c), N = -[R_c t_p]x Jl(r_c), M = R_c Jl(r_p), R = R_c
+//       [ N I ]          [ 0 R ]
+struct RigChain {
+  double J[9], N[9], M[9], R[9];
+};
+CC_HD void rig_chain(const double pose_p[6], const double ext[6], RigChain& c) {
+  double Jlp[9];
+  rodrigues(ext, c.R);
   left_jacobian(pose_p, Jlp);
-  left_jacobian(ext, Jlc);
-  mat3_mul(Rc, Jlp, M1);
+  left_jacobian(ext, c.J);
+  mat3_mul(c.R, Jlp, c.M);
   double s[3];
   CC_UNROLL
-  for (int i = 0; i < 3; ++i) s[i] = Rc[i * 3] * pose_p[3] + Rc[i * 3 + 1] * pose_p[4] + Rc[i * 3 + 2] * pose_p[5];
-  const double N[9] = {0.0, s[2], -s[1], -s[2], 0.0, s[0], s[1], -s[0], 0.0};   // -[s]x
-  double NJ[9];
-  mat3_mul(N, Jlc, NJ);
-  CC_UNROLL
-  for (int i = 0; i < 36; ++i) { A[i] = 0.0; B[i] = 0.0; }
-  CC_UNROLL
-  for (int i = 0; i < 3; ++i)
-    CC_UNROLL
-    for (int j = 0; j < 3; ++j) {
-      A[i * 6 + j] = Jlc[i * 3 + j];
-      A[(3 + i) * 6 + j] = NJ[i * 3 + j];
-      B[i * 6 + j] = M1[i * 3 + j];
-      B[(3 + i) * 6 + 3 + j] = Rc[i * 3 + j];
-    }
-  A[3 * 6 + 3] = 1.0; A[4 * 6 + 4] = 1.0; A[5 * 6 + 5] = 1.0;
+  for (int i = 0; i < 3; ++i) s[i] = c.R[i * 3] * pose_p[3] + c.R[i * 3 + 1] * pose_p[4] + c.R[i * 3 + 2] * pose_p[5];
+  const double X[9] = {0.0, s[2], -s[1], -s[2], 0.0, s[0], s[1], -s[0], 0.0};   // -[s]x
+  mat3_mul(X, c.J, c.N);
 }
 
-// One (pose, camera) view: local blocks -> rig blocks.
-//   Vp (21 upper)  = B^T V B          pose block contribution
-//   gp (6)         = B^T g
-//   Wp ((NI+6) x 6): rows 0..NI-1 = W B (intrinsics x pose), rows NI.. = A^T V B (extrinsic x pose)
-//   ge: [ U_ie = W A (NI x 6) | U_ee = A^T V A (21 upper) | b_e = A^T g (6) ]   (added into acc)
-template <int NI>
-CC_HD void rig_assemble_view(const double* Vl, const double* Wl, const double* gl, const double A[36],
-                             const double B[36], double* Vp, double* gp, double* Wp, double* acc) {
+// One (pose, camera) view: local blocks -> rig blocks, every product written out by the
+// block structure of A and B (half the multiplications of dense 6x6 congruences).  Two
+// halves, so that a device kernel can give them to different wavefronts (together they
+// need more registers than a lane has).
+//
+// Pose half:  Vp (21 upper) = B^T V B,  gp (6) = B^T g,  We (6 x 6) = A^T V B  (the
+// extrinsic rows NI .. NI+5 of Wp),  acc_e += [ U_ee = A^T V A (21 upper) | b_e = A^T g (6) ].
+CC_HD void rig_assemble_pose(const double* Vl, const double* gl, const RigChain& c, double* Vp, double* gp,
+                             double* We, double* acc_e) {
   double V[36];
   CC_UNROLL
   for (int i = 0; i < 6; ++i)
     CC_UNROLL
     for (int j = 0; j < 6; ++j) V[i * 6 + j] = Vl[i <= j ? tri(6, i, j) : tri(6, j, i)];
-  double VB[36], VA[36], T[36];
-  mat6_ab(V, B, VB);
-  mat6_ab(V, A, VA);
-  mat6_atb(B, VB, T);
+  double VB[36];
   CC_UNROLL
   for (int i = 0; i < 6; ++i)
     CC_UNROLL
-    for (int j = i; j < 6; ++j) Vp[tri(6, i, j)] = T[i * 6 + j];
-  mat6_atb(A, VB, T);                       // extrinsic x pose
-  CC_UNROLL
-  for (int i = 0; i < 36; ++i) Wp[NI * 6 + i] = T[i];
-  mat6_atb(A, VA, T);                       // extrinsic x extrinsic
+    for (int j = 0; j < 3; ++j) {
+      double sm = 0.0, sr = 0.0;
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) {
+        sm = fma(V[i * 6 + k], c.M[k * 3 + j], sm);
+        sr = fma(V[i * 6 + 3 + k], c.R[k * 3 + j], sr);
+      }
+      VB[i * 6 + j] = sm;
+      VB[i * 6 + 3 + j] = sr;
+    }
   CC_UNROLL
   for (int i = 0; i < 6; ++i)
     CC_UNROLL
-    for (int j = i; j < 6; ++j) acc[NI * 6 + tri(6, i, j)] += T[i * 6 + j];
+    for (int j = i; j < 6; ++j) {
+      double sv = 0.0;
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = i < 3 ? fma(c.M[k * 3 + i], VB[k * 6 + j], sv) : fma(c.R[k * 3 + i - 3], VB[(3 + k) * 6 + j], sv);
+      Vp[tri(6, i, j)] = sv;
+    }
   CC_UNROLL
-  for (int j = 0; j < 6; ++j) {
-    double sb = 0.0, sa = 0.0;
+  for (int i = 0; i < 3; ++i)
     CC_UNROLL
-    for (int k = 0; k < 6; ++k) { sb = fma(B[k * 6 + j], gl[k], sb); sa = fma(A[k * 6 + j], gl[k], sa); }
-    gp[j] = sb;
-    acc[NI * 6 + 21 + j] += sa;
+    for (int j = 0; j < 6; ++j) {
+      double sv = 0.0;
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = fma(c.J[k * 3 + i], VB[k * 6 + j], sv);
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = fma(c.N[k * 3 + i], VB[(3 + k) * 6 + j], sv);
+      We[i * 6 + j] = sv;
+      We[(3 + i) * 6 + j] = VB[(3 + i) * 6 + j];
+    }
+  // V A: the left 6 x 3 block; the right one is V itself
+  double VA[18];
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i)
+    CC_UNROLL
+    for (int j = 0; j < 3; ++j) {
+      double sv = 0.0;
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = fma(V[i * 6 + k], c.J[k * 3 + j], sv);
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = fma(V[i * 6 + 3 + k], c.N[k * 3 + j], sv);
+      VA[i * 3 + j] = sv;
+    }
+  CC_UNROLL
+  for (int i = 0; i < 3; ++i)
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) {
+      double sv = 0.0;
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = fma(c.J[k * 3 + i], j < 3 ? VA[k * 3 + j] : V[k * 6 + j], sv);
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sv = fma(c.N[k * 3 + i], j < 3 ? VA[(3 + k) * 3 + j] : V[(3 + k) * 6 + j], sv);
+      acc_e[tri(6, i, j)] += sv;
+    }
+  CC_UNROLL
+  for (int i = 3; i < 6; ++i)
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) acc_e[tri(6, i, j)] += V[i * 6 + j];
+  CC_UNROLL
+  for (int j = 0; j < 3; ++j) {
+    double sm = 0.0, sr = 0.0, sa = 0.0;
+    CC_UNROLL
+    for (int k = 0; k < 3; ++k) {
+      sm = fma(c.M[k * 3 + j], gl[k], sm);
+      sr = fma(c.R[k * 3 + j], gl[3 + k], sr);
+      sa = fma(c.J[k * 3 + j], gl[k], sa);
+    }
+    CC_UNROLL
+    for (int k = 0; k < 3; ++k) sa = fma(c.N[k * 3 + j], gl[3 + k], sa);
+    gp[j] = sm;
+    gp[3 + j] = sr;
+    acc_e[21 + j] += sa;
+    acc_e[21 + 3 + j] += gl[3 + j];
   }
+}
+
+// Intrinsics half:  Wi (NI x 6) = W B  (rows 0 .. NI-1 of Wp),  acc_i += U_ie = W A (NI x 6).
+template <int NI>
+CC_HD void rig_assemble_intr(const double* Wl, const RigChain& c, double* Wi, double* acc_i) {
   CC_UNROLL
   for (int a = 0; a < NI; ++a)
     CC_UNROLL
-    for (int j = 0; j < 6; ++j) {
-      double sb = 0.0, sa = 0.0;
+    for (int j = 0; j < 3; ++j) {
+      double sm = 0.0, sr = 0.0, sa = 0.0;
       CC_UNROLL
-      for (int k = 0; k < 6; ++k) { sb = fma(Wl[a * 6 + k], B[k * 6 + j], sb); sa = fma(Wl[a * 6 + k], A[k * 6 + j], sa); }
-      Wp[a * 6 + j] = sb;
-      acc[a * 6 + j] += sa;
+      for (int k = 0; k < 3; ++k) {
+        sm = fma(Wl[a * 6 + k], c.M[k * 3 + j], sm);
+        sr = fma(Wl[a * 6 + 3 + k], c.R[k * 3 + j], sr);
+        sa = fma(Wl[a * 6 + k], c.J[k * 3 + j], sa);
+      }
+      CC_UNROLL
+      for (int k = 0; k < 3; ++k) sa = fma(Wl[a * 6 + 3 + k], c.N[k * 3 + j], sa);
+      Wi[a * 6 + j] = sm;
+      Wi[a * 6 + 3 + j] = sr;
+      acc_i[a * 6 + j] += sa;
+      acc_i[a * 6 + 3 + j] += Wl[a * 6 + 3 + j];
     }
 }
 

@@ -12,6 +12,9 @@
 //       board poses of buffer 0 from the first camera that sees them and ext[0]
 //   int camcal_read_sync(double* dst_host, const double* src_dev, int n, void* stream)
 //   int camcal_write_sync(double* dst_dev, const double* src_host, int n, void* stream)
+//   int camcal_fork_streams(void* stream, int n, void** side_out)   side_out[0] = stream; the others start
+//       behind everything queued on stream (the emulator hands back `stream` n times)
+//   int camcal_join_streams(void* stream, int n, void** side)       stream continues behind all of them
 // and struct camcal_reader (camcal_driver.h).
 #pragma once
 #include <cmath>
@@ -29,15 +32,22 @@ int camcal_rig_init(const camcal_rig* rig, const camcal_comm* comm, void* stream
   const int nC = rig->n_cams, model = rig->model;
   if (camcal_n_intr(model) < 0) return CAMCAL_E_BADMODEL;
   // per-camera poses of every view at the guessed intrinsics (the single-camera kernels)
+  // -- the cameras are independent here: one stream each, joined before the pair sums
+  for (int c = 0; c < nC; ++c)
+    if (!rig->cam[c].pose || !rig->cam[c].pose_slot) return CAMCAL_E_BADARG;
+  void* side[CAMCAL_RIG_MAX_CAMS];
+  CAMCAL_DRV_TRY(camcal_fork_streams(stream, nC, side));
   int64_t so = 0;
-  for (int c = 0; c < nC; ++c) {
+  int rc_cam = 0;
+  for (int c = 0; c < nC && rc_cam == 0; ++c) {
     const camcal_rig_cam& k = rig->cam[c];
-    if (!k.pose || !k.pose_slot) return CAMCAL_E_BADARG;
     int32_t* st = rig->status ? rig->status + so : nullptr;
     so += k.tiles.n_slots;
-    CAMCAL_DRV_TRY(camcal_pose_init(model, &k.tiles, rig->intr[0] + c * 16, k.pose, st, stream));
-    CAMCAL_DRV_TRY(camcal_pose_refine(model, &k.tiles, rig->intr[0] + c * 16, k.pose, 20, 1e-10, nullptr, stream));
+    rc_cam = camcal_pose_init(model, &k.tiles, rig->intr[0] + c * 16, k.pose, st, side[c]);
+    if (rc_cam == 0) rc_cam = camcal_pose_refine(model, &k.tiles, rig->intr[0] + c * 16, k.pose, 20, 1e-10, nullptr, side[c]);
   }
+  CAMCAL_DRV_TRY(camcal_join_streams(stream, nC, side));      // also after a failed launch: nothing stays forked
+  if (rc_cam) return rc_cam;
   double* sums_dev = nullptr;
   CAMCAL_DRV_TRY(rig_pair_sums(rig, &sums_dev, stream));
   CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, sums_dev, (int64_t)nC * nC * 13, stream));

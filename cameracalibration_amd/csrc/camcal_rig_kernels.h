@@ -146,7 +146,10 @@ __global__ __launch_bounds__(64) void k_rig_expand(const double* __restrict__ re
   }
 }
 
-// chain rule to the rig parameters, all cameras (blockIdx.y); persistent waves per camera
+// chain rule to the rig parameters, all cameras (blockIdx.y); persistent waves per camera.
+// blockIdx.z = 0: the pose half of a view (Vp, gp, extrinsic rows of Wp, sums U_ee, b_e),
+// 1: the intrinsics half (rows 0 .. NI-1 of Wp, sum U_ie) -- camcal_rig.h.  As one body the
+// two held 477 doubles per lane and spilled 932 bytes of it to scratch memory (43 us on C4).
 template <int NI>
 __global__ __launch_bounds__(TPB) void k_rig_assemble(camcal_rig rg, int b, int rows_stride) {
   constexpr int NACC = NI * 6 + 21 + 6;
@@ -156,43 +159,65 @@ __global__ __launch_bounds__(TPB) void k_rig_assemble(camcal_rig rg, int b, int 
   const int n_waves = gridDim.x * WPB;
   const int lane = threadIdx.x & 63;
   const int64_t S = t.n_slots, P = rg.P;
-  double acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
   double e[6];
 #pragma unroll
   for (int c = 0; c < 6; ++c) e[c] = rg.ext[b][cam * 6 + c];
   const int32_t* __restrict__ slot_pose = rg.cam[cam].slot_pose;
-  const double* __restrict__ Vb = rg.cam[cam].V;
-  const double* __restrict__ Wb = rg.cam[cam].W;
-  const double* __restrict__ gb = rg.cam[cam].g;
   const double* __restrict__ rig_pose = rg.rig_pose[b];
-  double* __restrict__ Vp = rg.Vp[b] + (int64_t)cam * 21 * P;
-  double* __restrict__ gp = rg.gp[b] + (int64_t)cam * 6 * P;
   double* __restrict__ Wp = rg.Wp[b] + (int64_t)cam * (NI + 6) * 6 * P;
-  for (int tile = wave; tile < t.n_tiles; tile += n_waves) {
-    const int64_t slot = (int64_t)tile * LANES + lane;
-    const int idx = slot_pose[slot];
-    if (idx < 0) continue;
-    double pp[6], A[36], B[36], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
+  double* part = rg.scratch + (long long)cam * NACC * rows_stride + wave;
+  if (blockIdx.z == 0) {
+    const double* __restrict__ Vb = rg.cam[cam].V;
+    const double* __restrict__ gb = rg.cam[cam].g;
+    double* __restrict__ Vp = rg.Vp[b] + (int64_t)cam * 21 * P;
+    double* __restrict__ gp = rg.gp[b] + (int64_t)cam * 6 * P;
+    double acc[27];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    for (int tile = wave; tile < t.n_tiles; tile += n_waves) {
+      const int64_t slot = (int64_t)tile * LANES + lane;
+      const int idx = slot_pose[slot];
+      if (idx < 0) continue;
+      double pp[6], Vl[21], gl[6], oV[21], og[6], oW[36];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) Vl[i] = Vb[i * S + slot];
+      for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
 #pragma unroll
-    for (int i = 0; i < NI * 6; ++i) Wl[i] = Wb[i * S + slot];
+      for (int i = 0; i < 21; ++i) Vl[i] = Vb[i * S + slot];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) gl[i] = gb[i * S + slot];
-    rig_chain(pp, e, A, B);
-    rig_assemble_view<NI>(Vl, Wl, gl, A, B, oV, og, oW, acc);
+      for (int i = 0; i < 6; ++i) gl[i] = gb[i * S + slot];
+      RigChain ch;
+      rig_chain(pp, e, ch);
+      rig_assemble_pose(Vl, gl, ch, oV, og, oW, acc);
 #pragma unroll
-    for (int i = 0; i < 21; ++i) Vp[i * P + idx] = oV[i];
+      for (int i = 0; i < 21; ++i) Vp[i * P + idx] = oV[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
+      for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
 #pragma unroll
-    for (int i = 0; i < (NI + 6) * 6; ++i) Wp[i * P + idx] = oW[i];
+      for (int i = 0; i < 36; ++i) Wp[(NI * 6 + i) * P + idx] = oW[i];
+    }
+    wave_scatter_store<27>(acc, lane, part + (long long)NI * 6 * rows_stride, rows_stride);
+  } else {
+    const double* __restrict__ Wb = rg.cam[cam].W;
+    double acc[NI * 6];
+#pragma unroll
+    for (int i = 0; i < NI * 6; ++i) acc[i] = 0.0;
+    for (int tile = wave; tile < t.n_tiles; tile += n_waves) {
+      const int64_t slot = (int64_t)tile * LANES + lane;
+      const int idx = slot_pose[slot];
+      if (idx < 0) continue;
+      double pp[6], Wl[NI * 6], oW[NI * 6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) pp[c] = rig_pose[c * P + idx];
+#pragma unroll
+      for (int i = 0; i < NI * 6; ++i) Wl[i] = Wb[i * S + slot];
+      RigChain ch;
+      rig_chain(pp, e, ch);
+      rig_assemble_intr<NI>(Wl, ch, oW, acc);
+#pragma unroll
+      for (int i = 0; i < NI * 6; ++i) Wp[i * P + idx] = oW[i];
+    }
+    wave_scatter_store<NI * 6>(acc, lane, part, rows_stride);
   }
-  wave_scatter_store<NACC>(acc, lane, rg.scratch + (long long)cam * NACC * rows_stride + wave, rows_stride);
 }
 
 // Pose elimination: per board pose V = sum_c Vp_c (damped) = U^T U, Yt = U^-T Wp^T, z = U^-T g.
@@ -379,123 +404,182 @@ __global__ __launch_bounds__(TPB) void k_rig_backsub(int n_cams, int64_t P, cons
   wave_reduce_store<2>(acc, scratch, wave);
 }
 
-// Reduced solve of the rig on one wavefront.  The system (n <= 64) is built and Jacobi-
-// scaled in LDS (camcal_rig.h: rig_solve_build / rig_solve_scale); the Cholesky
-// factorisation then runs with row i of the matrix in lane i's registers: the pivot and
-// the column entries l_jk a trailing update needs are v_readlane broadcasts with constant
-// lane and register numbers (the loops are fully unrolled), so a step costs no LDS round
-// trip and no barrier (202 -> 73 us at n = 50).  Rows / columns beyond n are identity padding.
-__device__ __forceinline__ double lane_bcast_c(double x, int src) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
-                          __builtin_amdgcn_readlane(__double2loint(x), src));
+// Reduced solve of the rig on one workgroup of 16 x 16 threads.  The augmented matrix
+// [M ; rhs^T] (n + 1 <= 64 rows) lives in REGISTERS, cyclically: thread (tx, ty) owns the
+// entries (ty + 16a, tx + 16b), a, b < 4, with compile-time register numbers.  It is built
+// from the record (the entries of camcal_rig.h: rig_solve_build), Jacobi-scaled, and
+// factorised as L D L^T without square roots.  Step k: the owners of column k publish it
+// to LDS, one barrier, then every thread reads the pivot p_k, its four a_ik and four a_jk
+// and updates its entries, a_ij -= a_ik a_jk / p_k -- no LDS round trip of the matrix
+// itself, one barrier per step.  Entries of finished rows / columns are updated too and
+// never read again.  The right-hand side is row n, so the forward substitution is part
+// of the factorisation; the first wavefront then solves L^T x = y from the published
+// columns with x_k broadcast by v_readlane.  (The first version kept whole rows in one
+// wavefront's registers, fully unrolled: 50 KB of straight-line code that spent its 74 us
+// at n = 50 waiting for instruction fetch.)
+// Entry (i, j) of the augmented system as  fa * *pa + fc * *pc + id  with addresses that are
+// always valid, so that a thread's 16 entries are 32 independent loads (one round trip to
+// memory) instead of 16 branches with a load behind each.
+struct RigEntry {
+  const double* pa;
+  const double* pc;
+  double fa, fc, id;
+};
+__device__ __forceinline__ RigEntry rig_reduced_entry(int i, int j, int n, int NI, int n_cams,
+                                                      const double* __restrict__ rec, unsigned long long mask, double lam) {
+  RigEntry e = {rec, rec, 0.0, 0.0, 0.0};
+  if (j >= n || i > n) return e;
+  const int G = NI + 6;
+  const int NU = NI * (NI + 1) / 2, NV = NU + NI + 1, NX = NI * 6 + 27;
+  const double* Cm = rec + (long long)n_cams * (NV + NX) + 5;   // RigLayout::o_C
+  const double* d = Cm + (long long)n * n;
+  const int cj = j / G, b = j - cj * G;
+  const bool fj = (mask >> j) & 1ull;
+  if (i == n) {                                   // right-hand side
+    const double* glob = rec + (long long)cj * (NV + NX);
+    const double* rx = glob + NV;
+    if (fj) {
+      e.pa = b < NI ? glob + NU + b : rx + NI * 6 + 21 + (b - NI);
+      e.fa = 1.0;
+      e.pc = d + j;
+      e.fc = -1.0;
+    }
+    return e;
+  }
+  if (!fj || !((mask >> i) & 1ull)) {
+    e.id = (i == j) ? 1.0 : 0.0;
+    return e;
+  }
+  const int c = i / G, a = i - c * G;
+  if (c == cj) {
+    const double* glob = rec + (long long)c * (NV + NX);
+    const double* rx = glob + NV;
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    if (hi < NI) e.pa = glob + tri(NI, lo, hi);
+    else if (lo < NI) e.pa = rx + lo * 6 + (hi - NI);
+    else e.pa = rx + NI * 6 + tri(6, lo - NI, hi - NI);
+    e.fa = (i == j) ? 1.0 + lam : 1.0;
+  }
+  e.pc = Cm + i * n + j;
+  e.fc = -1.0;
+  return e;
 }
 
-__global__ __launch_bounds__(64) void k_rig_solve_reduced(int NI, int n_cams, const double* __restrict__ rec,
-                                                          unsigned long long mask, double lam,
-                                                          const double* __restrict__ intr_in,
-                                                          const double* __restrict__ ext_in,
-                                                          double* __restrict__ intr_out, double* __restrict__ ext_out,
-                                                          double* __restrict__ dG, double* __restrict__ stats) {
-  __shared__ RigSolveWs w;
-  constexpr int N = RIG_MAXN;
-  const int lane = threadIdx.x, n = n_cams * (NI + 6);
-  // the entries of rig_solve_build, one per lane and trip (coalesced reads of C, several in flight)
+__global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, const double* __restrict__ rec,
+                                                           unsigned long long mask, double lam,
+                                                           const double* __restrict__ intr_in,
+                                                           const double* __restrict__ ext_in,
+                                                           double* __restrict__ intr_out, double* __restrict__ ext_out,
+                                                           double* __restrict__ dG, double* __restrict__ stats) {
+  __shared__ double Lc[RIG_MAXN * RIG_LD];        // Lc[k * RIG_LD + i] = a_ik as published in step k
+  __shared__ double sc[RIG_MAXN], rpv[RIG_MAXN];
+  __shared__ int okf;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int n = n_cams * (NI + 6);
+  double v[4][4];
   {
-    const int G = NI + 6;
-    const int NU = NI * (NI + 1) / 2, NV = NU + NI + 1, NX = NI * 6 + 27;
-    const double* Cm = rec + (long long)n_cams * (NV + NX) + 5;   // RigLayout::o_C
-    const double* d = Cm + (long long)n * n;
-#pragma unroll 4
-    for (int e = lane; e < n * n; e += 64) {
-      const int i = e / n, j = e - i * n;
-      const int c = i / G, a = i - c * G, cj = j / G, b = j - cj * G;
-      const double* glob = rec + (long long)c * (NV + NX);
-      const double* rx = glob + NV;
-      double v;
-      if (!((mask >> i) & 1ull) || !((mask >> j) & 1ull)) {
-        v = (i == j) ? 1.0 : 0.0;
-      } else {
-        v = 0.0;
-        if (c == cj) {
-          const int lo = a < b ? a : b, hi = a < b ? b : a;
-          if (hi < NI) v = glob[tri(NI, lo, hi)];
-          else if (lo < NI) v = rx[lo * 6 + (hi - NI)];
-          else v = rx[NI * 6 + tri(6, lo - NI, hi - NI)];
-          if (i == j) v *= 1.0 + lam;
-        }
-        v -= Cm[e];
+    RigEntry en[4][4];
+    double va[4][4], vc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) en[a][b] = rig_reduced_entry(ty + 16 * a, tx + 16 * b, n, NI, n_cams, rec, mask, lam);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { va[a][b] = *en[a][b].pa; vc[a][b] = *en[a][b].pc; }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        // (the products are exact: fa is 1 except on the damped diagonal, fc is -1 or 0)
+        const double t = en[a][b].fa * va[a][b];
+        v[a][b] = (en[a][b].fa != 0.0 ? t : 0.0) + (en[a][b].fc != 0.0 ? -vc[a][b] : 0.0) + en[a][b].id;
       }
-      w.A[i * RIG_LD + j] = v;
+  }
+  if (tx == ty) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int i = ty + 16 * a;
+      const double dii = v[a][a];
+      if (i < n) sc[i] = dii > 0.0 ? 1.0 / sqrt(dii) : 1.0;
+    }
+  }
+  if (tid == 0) { sc[n] = 1.0; okf = 1; }
+  __syncthreads();
+  {
+    double si[4], sj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      si[a] = ty + 16 * a <= n ? sc[ty + 16 * a] : 0.0;
+      sj[a] = tx + 16 * a < n ? sc[tx + 16 * a] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) v[a][b] *= si[a] * sj[b];
+  }
+  for (int k = 0; k < n; ++k) {
+    const int kb = k >> 4;                           // uniform
+    if (tx == (k & 15)) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        Lc[k * RIG_LD + ty + 16 * a] = kb == 0 ? v[a][0] : kb == 1 ? v[a][1] : kb == 2 ? v[a][2] : v[a][3];
     }
     __syncthreads();
-    if (lane < n) {
-      const int c = lane / G, a = lane - c * G;
-      const double* glob = rec + (long long)c * (NV + NX);
-      const double* rx = glob + NV;
-      double r = 0.0;
-      if ((mask >> lane) & 1ull) r = (a < NI ? glob[NU + a] : rx[NI * 6 + 21 + (a - NI)]) - d[lane];
-      w.rhs[lane] = r;
-      const double dii = w.A[lane * RIG_LD + lane];
-      w.sc[lane] = dii > 0.0 ? 1.0 / sqrt(dii) : 1.0;
+    const double p = Lc[k * RIG_LD + k];
+    const bool good = p > 0.0;
+    // 1 / p from v_rcp_f64 (2^-23 or better): with e = 1 - p r0, r = r0 (1 + e + e^2) leaves e^3
+    const double r0 = __builtin_amdgcn_rcp(good ? p : 1.0);
+    const double er = fma(-p, r0, 1.0);
+    const double rp = good ? fma(r0, fma(er, er, er), r0) : 0.0;
+    if (tid == 0) {
+      rpv[k] = rp;
+      if (!good) okf = 0;
     }
-    if (lane == 0) w.ok = 1;
-  }
-  __syncthreads();
-  rig_solve_scale(lane, 64, n, w);
-  __syncthreads();
-  double row[N];
+    double aik[4], ajk[4];
 #pragma unroll
-  for (int j = 0; j < N; ++j) row[j] = (lane < n && j < n) ? w.A[lane * RIG_LD + j] : (lane == j ? 1.0 : 0.0);
-  double y = lane < n ? w.rhs[lane] : 0.0;
-  double my_inv = 1.0;               // 1 / L_ii of this lane's row
-  bool ok = true;
+    for (int a = 0; a < 4; ++a) {
+      aik[a] = Lc[k * RIG_LD + ty + 16 * a] * rp;
+      ajk[a] = Lc[k * RIG_LD + tx + 16 * a];
+    }
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < n) {                     // uniform
-      const double p = lane_bcast_c(row[k], k);
-      const bool good = p > 0.0;
-      double rt;
-      const double rs = fast_rsqrt(good ? p : 1.0, rt);          // 1/sqrt(p) and sqrt(p), <= 2 ulp
-      const double inv = good ? rs : 0.0;
-      ok = ok && good;
-      const double lik = lane > k ? row[k] * inv : 0.0;          // column k of L below the diagonal
-      if (lane > k) row[k] = lik;
-      if (lane == k) { row[k] = good ? rt : 1.0; my_inv = good ? inv : 1.0; }
+    for (int a = 0; a < 4; ++a) {
+      if (16 * a + 15 <= k) continue;                // uniform: block row finished
 #pragma unroll
-      for (int j = k + 1; j < N; ++j) row[j] = fma(-lik, lane_bcast_c(lik, j), row[j]);   // A_ij -= l_ik l_jk
+      for (int b = 0; b <= a; ++b) {
+        if (16 * b + 15 <= k) continue;
+        v[a][b] = fma(-aik[a], ajk[b], v[a][b]);
+      }
     }
   }
-  // L y = rhs, column by column
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (k < n) {
-      const double yk = lane_bcast_c(y, k) * lane_bcast_c(my_inv, k);
-      if (lane == k) y = yk;
-      if (lane > k) y = fma(-row[k], yk, y);
-    }
-  }
-  // L^T x = y needs the columns of L: transpose through LDS
   __syncthreads();
+  if (tid >= 64) return;
+  // L^T x = y with the unscaled columns: x_k = (a_nk - sum_{i > k} a_ik x_i) / p_k.  Lane j keeps
+  // z_j = y_j / p_j and its column pre-divided, so a step is one broadcast and one fma:
+  //   x_k = z_k,   z_j -= (a_kj / p_j) x_k   (j < k).
+  const int lane = tid;
+  const double rpl = lane < n ? rpv[lane] : 0.0;
+  double col[RIG_MAXN];
 #pragma unroll
-  for (int j = 0; j < N; ++j) w.A[lane * RIG_LD + j] = row[j];
-  __syncthreads();
+  for (int k = 0; k < RIG_MAXN; ++k) col[k] = (k < n && lane < k) ? Lc[lane * RIG_LD + k] * rpl : 0.0;
+  double y = lane < n ? Lc[lane * RIG_LD + n] * rpl : 0.0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) row[j] = w.A[j * RIG_LD + lane];   // row[j] = L_j,lane
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) {
-    if (k < n) {
-      const double xk = lane_bcast_c(y, k) * lane_bcast_c(my_inv, k);
-      if (lane == k) y = xk;
-      if (lane < k) y = fma(-row[k], xk, y);
+  for (int k = RIG_MAXN - 1; k >= 1; --k) {
+    if (k < n) {                                   // uniform
+      const double xk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(y), k),
+                                         __builtin_amdgcn_readlane(__double2loint(y), k));
+      y = fma(-col[k], xk, y);                     // col[k] = 0 for lanes >= k
     }
   }
   // rig_solve_finish, one parameter per lane: out = in - dG, stats = [||dG||^2, ||globals_in||^2];
   // a failed factorisation gives NaN so that the LM driver rejects the step
+  const bool ok = okf != 0;
   double s0 = 0.0, s1 = 0.0;
   if (lane < n) {
     const int G = NI + 6, c = lane / G, a = lane - c * G;
     const double bad = ok ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
-    const double dx = ((mask >> lane) & 1ull) ? y * w.sc[lane] + bad : 0.0;
+    const double dx = ((mask >> lane) & 1ull) ? y * sc[lane] + bad : 0.0;
     dG[lane] = dx;
     const double prev = a < NI ? intr_in[c * 16 + a] : ext_in[c * 6 + (a - NI)];
     if (a < NI) intr_out[c * 16 + a] = prev - dx;
@@ -582,6 +666,7 @@ inline int rig_ok(const camcal_rig* r) {
 // for a single camera, 4 up to 2048 tiles (131072 views: C4 is 500 tiles -- one lane per view
 // would leave half the SIMDs idle and walk 88 corners serially), 1 above.  A camera's
 // lanes_per_view field forces the mapping (tests).
+constexpr int RIG_GROUP16_MAX_TILES = 128;     // measured on C4-shaped rigs: 4 lanes per view are ahead of 16 from here
 constexpr int RIG_GROUP4_MAX_TILES = 2048;
 inline int rig_group_lanes(const camcal_rig* r) {
   int total = 0, forced = 0;
@@ -589,10 +674,10 @@ inline int rig_group_lanes(const camcal_rig* r) {
     total += r->cam[c].tiles.n_tiles;
     if (r->cam[c].tiles.lanes_per_view) forced = r->cam[c].tiles.lanes_per_view;
   }
-  const int by_size = total <= GROUP64_MAX_TILES ? 64 : total <= GROUP16_MAX_TILES ? 16 : total <= RIG_GROUP4_MAX_TILES ? 4 : 1;
+  const int by_size = total <= GROUP64_MAX_TILES ? 64 : total <= RIG_GROUP16_MAX_TILES ? 16 : total <= RIG_GROUP4_MAX_TILES ? 4 : 1;
   if (forced == 1) return 1;
   if (forced == 64) return total <= GROUP64_MAX_TILES ? 64 : by_size;
-  if (forced == 16) return total <= GROUP16_MAX_TILES ? 16 : by_size;
+  if (forced == 16) return total <= RIG_GROUP16_MAX_TILES ? 16 : by_size;
   return by_size;
 }
 inline bool rig_planar(const camcal_rig* r) {
@@ -630,7 +715,7 @@ int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_hos
   int64_t ev = 0;                                   // evaluation partials: up to 64 per tile (grouped small sets)
   for (int c = 0; c < n_cams; ++c) {
     const int64_t nt = n_tiles_host[c] > 0 ? n_tiles_host[c] : 0;
-    ev += (int64_t)MAX_NV * (nt <= GROUP64_MAX_TILES ? nt * 64 : nt <= GROUP16_MAX_TILES ? nt * 16
+    ev += (int64_t)MAX_NV * (nt <= GROUP64_MAX_TILES ? nt * 64 : nt <= RIG_GROUP16_MAX_TILES ? nt * 16
                                                                  : nt <= RIG_GROUP4_MAX_TILES ? nt * 4 : nt);
   }
   const int64_t as = (int64_t)n_cams * MAX_NV * MAX_WAVES;                   // chain-rule partials
@@ -685,8 +770,8 @@ int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream) {
   const int nacc = L.NX;
   RigParts ap;
   for (int c = 0; c < CAMCAL_RIG_MAX_CAMS; ++c) { ap.off[c] = (long long)c * nacc * nw; ap.np[c] = nw; }
-  if (L.NI == 9) hipLaunchKernelGGL(k_rig_assemble<9>, dim3(pb, nC), bl, 0, s, *rig, b, nw);
-  else hipLaunchKernelGGL(k_rig_assemble<8>, dim3(pb, nC), bl, 0, s, *rig, b, nw);
+  if (L.NI == 9) hipLaunchKernelGGL(k_rig_assemble<9>, dim3(pb, nC, 2), bl, 0, s, *rig, b, nw);
+  else hipLaunchKernelGGL(k_rig_assemble<8>, dim3(pb, nC, 2), bl, 0, s, *rig, b, nw);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_rig_finalize, dim3(nacc, nC), bl, 0, s, rig->scratch, ap, rig->rec[b] + L.NV, L.per);
   HIP_TRY(hipGetLastError());
@@ -719,7 +804,7 @@ int camcal_rig_solve(const camcal_rig* rig, int b, const uint8_t* mask_host, dou
   unsigned long long mask = 0;
   for (int i = 0; i < L.n; ++i)
     if (mask_host[i]) mask |= 1ull << i;
-  hipLaunchKernelGGL(k_rig_solve_reduced, dim3(1), dim3(64), 0, (hipStream_t)stream, ni, rig->n_cams, rig->rec[b], mask,
+  hipLaunchKernelGGL(k_rig_solve_reduced, dim3(1), dim3(TPB), 0, (hipStream_t)stream, ni, rig->n_cams, rig->rec[b], mask,
                      lam, rig->intr[b], rig->ext[b], rig->intr[out], rig->ext[out], rig->dG, rig->rec[out] + L.o_gstats);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -207,13 +207,15 @@ void rig_assemble_cam(const camcal_rig* rg, int b, int cam, double* rec_ext) {
   for (int64_t slot = 0; slot < S; ++slot) {
     const int idx = k.slot_pose[slot];
     if (idx < 0) continue;
-    double pp[6], A[36], B[36], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
+    double pp[6], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
     for (int c = 0; c < 6; ++c) pp[c] = rg->rig_pose[b][c * P + idx];
     for (int i = 0; i < 21; ++i) Vl[i] = k.V[i * S + slot];
     for (int i = 0; i < NI * 6; ++i) Wl[i] = k.W[i * S + slot];
     for (int i = 0; i < 6; ++i) gl[i] = k.g[i * S + slot];
-    rig_chain(pp, rg->ext[b] + cam * 6, A, B);
-    rig_assemble_view<NI>(Vl, Wl, gl, A, B, oV, og, oW, acc);
+    RigChain ch;
+    rig_chain(pp, rg->ext[b] + cam * 6, ch);
+    rig_assemble_pose(Vl, gl, ch, oV, og, oW + NI * 6, acc + NI * 6);
+    rig_assemble_intr<NI>(Wl, ch, oW, acc);
     for (int i = 0; i < 21; ++i) Vp[i * P + idx] = oV[i];
     for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
     for (int i = 0; i < (NI + 6) * 6; ++i) Wp[i * P + idx] = oW[i];
@@ -644,6 +646,11 @@ int camcal_write_sync(double* dst, const double* src_host, int n, void*) {
   std::memcpy(dst, src_host, (size_t)n * sizeof(double));
   return 0;
 }
+int camcal_fork_streams(void* stream, int n, void** side_out) {   // no streams on the host: all the same
+  for (int i = 0; i < n; ++i) side_out[i] = stream;
+  return 0;
+}
+int camcal_join_streams(void*, int, void**) { return 0; }
 }  // namespace
 #include "../../cameracalibration_amd/csrc/camcal_driver.h"
 #include "../../cameracalibration_amd/csrc/camcal_rig_driver.h"
