@@ -84,10 +84,17 @@ int camcal_rig_lm(const camcal_rig* rig, const uint8_t* mask_host, int max_iter,
       CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rig->rec[cur] + L.o_C, (int64_t)L.n * L.n + L.n, stream));
       CAMCAL_DRV_TRY(camcal_rig_solve(rig, cur, mask_host, lam, tri, stream));
       CAMCAL_DRV_TRY(camcal_rig_backsub(rig, cur, lam, tri, stream));
-      CAMCAL_DRV_TRY(camcal_rig_evaluate(rig, tri, stream));
-      // records, cost and pose-step norms of the trial point: one message
-      CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rig->rec[tri], L.o_gstats, stream));
-      CAMCAL_DRV_TRY(rd.begin(rig->rec[tri] + L.o_cost, 5, 0, stream));
+      if (comm) {
+        CAMCAL_DRV_TRY(camcal_rig_evaluate(rig, tri, stream));
+        // records, cost and pose-step norms of the trial point: one message
+        CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rig->rec[tri], L.o_gstats, stream));
+        CAMCAL_DRV_TRY(rd.begin(rig->rec[tri] + L.o_cost, 5, 0, stream));
+      } else {
+        // one process: the cost travels to the host while the chain rule of the trial point runs
+        CAMCAL_DRV_TRY(camcal_rig_residuals(rig, tri, stream));
+        CAMCAL_DRV_TRY(rd.begin(rig->rec[tri] + L.o_cost, 5, 0, stream));
+        CAMCAL_DRV_TRY(camcal_rig_chain(rig, tri, stream));
+      }
       CAMCAL_DRV_TRY(rd.end(back, 5));
       err = back[0];
       if (err <= prev_err) break;                  // NaN (failed factorisation) rejects the step

@@ -727,7 +727,7 @@ int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_hos
   return m + (int64_t)CAMCAL_RIG_MAX_CAMS * MAX_NV + 256;                    // + reduced values / small records
 }
 
-int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream) {
+int camcal_rig_residuals(const camcal_rig* rig, int b, void* stream) {
   if (!rig_ok(rig) || (b != 0 && b != 1)) return CAMCAL_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const int nC = rig->n_cams, model = rig->model;
@@ -765,6 +765,15 @@ int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream) {
   if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_rig_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, nC, rig->rec[b], L.per, L.o_cost);
   else hipLaunchKernelGGL(k_rig_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, nC, rig->rec[b], L.per, L.o_cost);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_rig_chain(const camcal_rig* rig, int b, void* stream) {
+  if (!rig_ok(rig) || (b != 0 && b != 1)) return CAMCAL_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int nC = rig->n_cams;
+  const RigLayout L(camcal_n_intr(rig->model), nC);
+  const dim3 bl(TPB);
   // chain rule: per-camera sums [U_ie | U_ee | b_e] straight into the records
   const int pb = rig_persistent_blocks(rig), nw = pb * WPB;
   const int nacc = L.NX;
@@ -776,6 +785,11 @@ int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream) {
   hipLaunchKernelGGL(k_rig_finalize, dim3(nacc, nC), bl, 0, s, rig->scratch, ap, rig->rec[b] + L.NV, L.per);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream) {
+  const int rc = camcal_rig_residuals(rig, b, stream);
+  return rc ? rc : camcal_rig_chain(rig, b, stream);
 }
 
 int camcal_rig_eliminate(const camcal_rig* rig, int b, double lam, void* stream) {

@@ -327,6 +327,12 @@ int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_hos
  * chain rule to the rig parameters: rec[b] records + cost, Vp/gp/Wp[b].  The caller zeroes
  * Vp, gp, Wp ONCE (which poses a camera sees never changes; unseen entries stay zero). */
 int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream);
+/* The two halves of camcal_rig_evaluate, for a caller that wants the cost early (the LM
+ * loop reads it back while the chain rule runs): residuals = per-camera evaluation ->
+ * V/W/g of every camera, the [U|b|cost] records and the cost of rec[b]; chain = chain rule
+ * -> Vp/gp/Wp[b] and the extrinsic records of rec[b].  evaluate = residuals, then chain. */
+int camcal_rig_residuals(const camcal_rig* rig, int b, void* stream);
+int camcal_rig_chain(const camcal_rig* rig, int b, void* stream);
 
 /* Pose elimination at damping lam: per board pose V = sum_c Vp_c (diag*(1+lam)) = U^T U,
  * Yt = U^-T Wp^T, z = U^-T g; then C = Y^T Y and d = Y^T z on the matrix cores

@@ -408,7 +408,7 @@ int64_t camcal_rig_rec_len(int model, int n_cams) {
   return RigLayout(ni, n_cams).total;
 }
 int64_t camcal_rig_scratch_len(int, int, const int32_t*, int64_t) { return 16 * 13 + 64; }
-int camcal_rig_evaluate(const camcal_rig* rg, int b, void*) {
+int camcal_rig_residuals(const camcal_rig* rg, int b, void*) {
   const int ni = camcal_n_intr(rg->model);
   const RigLayout L(ni, rg->n_cams);
   double cost = 0.0;
@@ -418,17 +418,28 @@ int camcal_rig_evaluate(const camcal_rig* rg, int b, void*) {
       double red[IntrAcc<PINHOLE>::NR];
       rig_eval_cam<PINHOLE>(rg, b, c, red);
       IntrAcc<PINHOLE>::expand(red, glob);
-      rig_assemble_cam<9>(rg, b, c, glob + L.NV);
     } else {
       double red[IntrAcc<FISHEYE>::NR];
       rig_eval_cam<FISHEYE>(rg, b, c, red);
       IntrAcc<FISHEYE>::expand(red, glob);
-      rig_assemble_cam<8>(rg, b, c, glob + L.NV);
     }
     cost += glob[L.NV - 1];
   }
   rg->rec[b][L.o_cost] = cost;
   return 0;
+}
+int camcal_rig_chain(const camcal_rig* rg, int b, void*) {
+  const RigLayout L(camcal_n_intr(rg->model), rg->n_cams);
+  for (int c = 0; c < rg->n_cams; ++c) {
+    double* glob = rg->rec[b] + c * L.per;
+    if (rg->model == 0) rig_assemble_cam<9>(rg, b, c, glob + L.NV);
+    else rig_assemble_cam<8>(rg, b, c, glob + L.NV);
+  }
+  return 0;
+}
+int camcal_rig_evaluate(const camcal_rig* rg, int b, void* stream) {
+  const int rc = camcal_rig_residuals(rg, b, stream);
+  return rc ? rc : camcal_rig_chain(rg, b, stream);
 }
 int camcal_rig_eliminate(const camcal_rig* rg, int b, double lam, void*) {
   const int ni = camcal_n_intr(rg->model);

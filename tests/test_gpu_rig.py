@@ -79,7 +79,7 @@ def test_rig_solve_matches_oracle_gpu(dev):
     R = small_rig()
     objs, imgs = R.as_lists()
     Ks, Ds = R.guess_matrices()
-    info = {}
+    info = {"init": True}
     out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _device_override=dev,
                             _info=info)
     rms, intr, ext, poses, oi = OR.rig_calibrate("fisheye", objs, imgs, R.intr_guess, max_iter=50, eps=1e-7)

@@ -80,7 +80,7 @@ def test_emulated_rig_matches_oracle(emu):
     R = small_rig()
     objs, imgs = R.as_lists()
     Ks, Ds = R.guess_matrices()
-    info = {}
+    info = {"init": True}
     out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _lib_override=emu,
                             _device_override=CPU, _info=info)
     log = []
