@@ -186,7 +186,7 @@ CC_HD void rig_assemble_intr(const double* Wl, const RigChain& c, double* Wi, do
 // Returns false when no camera sees the pose (all-zero block).
 template <int G>
 CC_HD bool rig_pose_factor(int n_cams, const double* Vp_all, const double* gp_all, long long P, long long p,
-                           double lam, double U[21], double g[6]) {
+                           double lam, double U[21], double g[6], double inv_diag[6]) {
   CC_UNROLL
   for (int e = 0; e < 21; ++e) U[e] = 0.0;
   CC_UNROLL
@@ -201,7 +201,7 @@ CC_HD bool rig_pose_factor(int n_cams, const double* Vp_all, const double* gp_al
   CC_UNROLL
   for (int i = 0; i < 6; ++i) { tr += U[tri(6, i, i)]; U[tri(6, i, i)] *= 1.0 + lam; }
   if (!(tr > 0.0)) return false;
-  return chol6(U);
+  return chol6(U, inv_diag);
 }
 
 // ---------------------------------------------------------------------------

@@ -226,30 +226,45 @@ __global__ __launch_bounds__(TPB) void k_rig_assemble(camcal_rig rg, int b, int 
 // Yt keeps the pose index fastest: lane-consecutive stores coalesce and k_rig_gram reads
 // runs of poses.
 constexpr int RIG_SCHUR_CHUNK = 8;
+constexpr int RIG_FACTOR_ROWS = 27;                // U (21) | 1 / U_ii (6) per pose, kept for camcal_rig_backsub
 template <int G>
 __global__ __launch_bounds__(TPB) void k_rig_pose_schur(int n_cams, int64_t P, const double* __restrict__ Vp_all,
                                                         const double* __restrict__ gp_all,
                                                         const double* __restrict__ Wp_all, double lam,
-                                                        double* __restrict__ Yt, double* __restrict__ z) {
+                                                        double* __restrict__ Yt, double* __restrict__ z,
+                                                        double* __restrict__ factor) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  double U[21], g[6];
-  const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, g);
   const int ld = n_cams * G;
+  // all columns of the chunk are loaded before the first is used: one memory latency per
+  // chunk instead of one per column (the loads were most of this kernel)
+  const int v0 = blockIdx.y * RIG_SCHUR_CHUNK;
+  double y[RIG_SCHUR_CHUNK][6];
+#pragma unroll
+  for (int c = 0; c < RIG_SCHUR_CHUNK; ++c) {
+    const int v = v0 + c < ld ? v0 + c : ld - 1;   // v = cam * G + a; clamped columns are not stored
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y[c][k] = Wp_all[((int64_t)v * 6 + k) * P + p];
+  }
+  double U[21], g[6], id[6];
+  const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, g, id);
   if (blockIdx.y == 0) {
-    if (ok) chol6_fwd(U, g);
+    if (ok) chol6_fwd(U, id, g);
 #pragma unroll
     for (int k = 0; k < 6; ++k) z[k * P + p] = ok ? g[k] : 0.0;
+    // a pose no camera sees keeps a zero factor: its step comes out as zero
+#pragma unroll
+    for (int k = 0; k < 21; ++k) factor[k * P + p] = ok ? U[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) factor[(21 + k) * P + p] = ok ? id[k] : 0.0;
   }
-  const int v0 = blockIdx.y * RIG_SCHUR_CHUNK;
-  const int v1 = v0 + RIG_SCHUR_CHUNK < ld ? v0 + RIG_SCHUR_CHUNK : ld;
-  for (int v = v0; v < v1; ++v) {                 // v = c * G + a
-    double y[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) y[k] = Wp_all[((int64_t)v * 6 + k) * P + p];
-    if (ok) chol6_fwd(U, y);
+  for (int c = 0; c < RIG_SCHUR_CHUNK; ++c) {
+    const int v = v0 + c;
+    if (v >= ld) break;
+    if (ok) chol6_fwd(U, id, y[c]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Yt[((int64_t)v * 6 + k) * P + p] = ok ? y[k] : 0.0;
+    for (int k = 0; k < 6; ++k) Yt[((int64_t)v * 6 + k) * P + p] = ok ? y[c][k] : 0.0;
   }
 }
 
@@ -349,32 +364,51 @@ __global__ __launch_bounds__(TPB) void k_rig_gram_finalize(int n, int n_waves, c
   }
 }
 
-// Four lanes share a pose: each subtracts a quarter of the Wp^T dG columns from its copy of
-// the right-hand side (the walk over all n columns by one lane was the whole cost), the four
-// partial sums meet by two exchanges, the first lane of the quad solves and stores.
-template <int G>
-__global__ __launch_bounds__(TPB) void k_rig_backsub(int n_cams, int64_t P, const double* __restrict__ Vp_all,
-                                                     const double* __restrict__ gp_all,
-                                                     const double* __restrict__ Wp_all, double lam,
+// d_p = U^-1 (z_p - Y_p dG) with the factor U, z = U^-T g and Y = U^-T Wp^T that the pose
+// elimination left behind (no second factorisation, no walk over Vp / gp).  Four lanes share
+// a pose: each takes a quarter of the n columns of Y, loaded RIG_BS_UNROLL at a time ahead
+// of their use; the partial sums meet by two exchanges, the first lane of the quad solves.
+constexpr int RIG_BS_UNROLL = 8;
+__global__ __launch_bounds__(TPB) void k_rig_backsub(int n, int64_t P, const double* __restrict__ Yt,
+                                                     const double* __restrict__ z, const double* __restrict__ factor,
                                                      const double* __restrict__ dG, const double* __restrict__ pose_in,
                                                      double* __restrict__ pose_out, double* __restrict__ scratch) {
   const int wave = blockIdx.x * WPB + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * WPB;
   const int lane = threadIdx.x & 63, sub = lane >> 4, pl = lane & 15;      // sub: which quarter of the columns
-  const int n = n_cams * G, per = (n + 3) / 4;
+  const int per = (n + 3) / 4;
   const int v0 = sub * per, v1 = v0 + per < n ? v0 + per : n;
   double acc[2] = {0.0, 0.0};
   const int64_t n_iter = (P + (int64_t)n_waves * 16 - 1) / ((int64_t)n_waves * 16);   // uniform trip count
   for (int64_t it = 0; it < n_iter; ++it) {
     const int64_t p = (it * n_waves + wave) * 16 + pl;
     const bool live = p < P;
-    double part[6] = {0, 0, 0, 0, 0, 0};
-    if (live) {
-      for (int v = v0; v < v1; ++v) {
-        const double dv = dG[v];
+    const int64_t pc = live ? p : P - 1;           // dead lanes read a valid pose and store nothing
+    double U[21], id[6], rhs[6], prev[6];
+    if (sub == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) part[k] = fma(Wp_all[((int64_t)v * 6 + k) * P + p], dv, part[k]);
+      for (int k = 0; k < 21; ++k) U[k] = factor[k * P + pc];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        id[k] = factor[(21 + k) * P + pc];
+        rhs[k] = z[k * P + pc];
+        prev[k] = pose_in[k * P + pc];
       }
+    }
+    double part[6] = {0, 0, 0, 0, 0, 0};
+    for (int vb = v0; vb < v1; vb += RIG_BS_UNROLL) {
+      double w[RIG_BS_UNROLL][6], dv[RIG_BS_UNROLL];
+#pragma unroll
+      for (int c = 0; c < RIG_BS_UNROLL; ++c) {
+        const int v = vb + c < v1 ? vb + c : v1 - 1;
+        dv[c] = vb + c < v1 ? dG[v] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) w[c][k] = Yt[((int64_t)v * 6 + k) * P + pc];
+      }
+#pragma unroll
+      for (int c = 0; c < RIG_BS_UNROLL; ++c)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) part[k] = fma(w[c][k], dv[c], part[k]);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -382,21 +416,13 @@ __global__ __launch_bounds__(TPB) void k_rig_backsub(int n_cams, int64_t P, cons
       part[k] += __shfl_xor(part[k], 32, 64);
     }
     if (live && sub == 0) {
-      double U[21], rhs[6], prev[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) prev[k] = pose_in[k * P + p];
-      const bool ok = rig_pose_factor<G>(n_cams, Vp_all, gp_all, P, p, lam, U, rhs);
-      if (ok) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) rhs[k] -= part[k];
-        chol6_fwd(U, rhs);
-        chol6_bwd(U, rhs);
-      }
+      for (int k = 0; k < 6; ++k) rhs[k] -= part[k];
+      chol6_bwd(U, id, rhs);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const double dd = ok ? rhs[k] : 0.0;
-        pose_out[k * P + p] = prev[k] - dd;
-        acc[0] += dd * dd;
+        pose_out[k * P + p] = prev[k] - rhs[k];
+        acc[0] += rhs[k] * rhs[k];
         acc[1] += prev[k] * prev[k];
       }
     }
@@ -404,19 +430,6 @@ __global__ __launch_bounds__(TPB) void k_rig_backsub(int n_cams, int64_t P, cons
   wave_reduce_store<2>(acc, scratch, wave);
 }
 
-// Reduced solve of the rig on one workgroup of 16 x 16 threads.  The augmented matrix
-// [M ; rhs^T] (n + 1 <= 64 rows) lives in REGISTERS, cyclically: thread (tx, ty) owns the
-// entries (ty + 16a, tx + 16b), a, b < 4, with compile-time register numbers.  It is built
-// from the record (the entries of camcal_rig.h: rig_solve_build), Jacobi-scaled, and
-// factorised as L D L^T without square roots.  Step k: the owners of column k publish it
-// to LDS, one barrier, then every thread reads the pivot p_k, its four a_ik and four a_jk
-// and updates its entries, a_ij -= a_ik a_jk / p_k -- no LDS round trip of the matrix
-// itself, one barrier per step.  Entries of finished rows / columns are updated too and
-// never read again.  The right-hand side is row n, so the forward substitution is part
-// of the factorisation; the first wavefront then solves L^T x = y from the published
-// columns with x_k broadcast by v_readlane.  (The first version kept whole rows in one
-// wavefront's registers, fully unrolled: 50 KB of straight-line code that spent its 74 us
-// at n = 50 waiting for instruction fetch.)
 // Entry (i, j) of the augmented system as  fa * *pa + fc * *pc + id  with addresses that are
 // always valid, so that a thread's 16 entries are 32 independent loads (one round trip to
 // memory) instead of 16 branches with a load behind each.
@@ -694,6 +707,29 @@ inline int rig_persistent_blocks(const camcal_rig* r) {
   const int g = (rig_max_tiles(r) + WPB - 1) / WPB;
   return g < MAX_WAVES / WPB ? g : MAX_WAVES / WPB;
 }
+// scratch = [ work area shared by the stages | pose factors (RIG_FACTOR_ROWS x P), written by
+// camcal_rig_eliminate and read by camcal_rig_backsub ]
+inline int64_t rig_work_len(int n_cams, const int32_t* n_tiles, int64_t P) {
+  (void)P;
+  int64_t ev = 0;                                   // evaluation partials: up to 64 per tile (grouped small sets)
+  for (int c = 0; c < n_cams; ++c) {
+    const int64_t nt = n_tiles[c] > 0 ? n_tiles[c] : 0;
+    ev += (int64_t)MAX_NV * (nt <= GROUP64_MAX_TILES ? nt * 64 : nt <= RIG_GROUP16_MAX_TILES ? nt * 16
+                                                                 : nt <= RIG_GROUP4_MAX_TILES ? nt * 4 : nt);
+  }
+  const int64_t as = (int64_t)n_cams * MAX_NV * MAX_WAVES;                   // chain-rule partials
+  const int64_t gr = (int64_t)RIG_GRAM_MAX_WAVES * RIG_GRAM_VALS;            // gram partials
+  const int64_t in = (int64_t)n_cams * n_cams * 13 * (MAX_WAVES + 1);        // pair sums
+  int64_t m = ev > as ? ev : as;
+  m = m > gr ? m : gr;
+  m = m > in ? m : in;
+  return m + (int64_t)CAMCAL_RIG_MAX_CAMS * MAX_NV + 256;                    // + reduced values / small records
+}
+inline double* rig_factor_ptr(const camcal_rig* r) {
+  int32_t nt[CAMCAL_RIG_MAX_CAMS];
+  for (int c = 0; c < r->n_cams; ++c) nt[c] = r->cam[c].tiles.n_tiles;
+  return r->scratch + rig_work_len(r->n_cams, nt, r->P);
+}
 inline int rig_gram_waves(int64_t P) {
   const int64_t ch = (P + 15) / 16;
   return (int)(ch < RIG_GRAM_MAX_WAVES ? ch : RIG_GRAM_MAX_WAVES);
@@ -712,19 +748,7 @@ int64_t camcal_rig_rec_len(int model, int n_cams) {
 int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_host, int64_t P) {
   const int ni = camcal_n_intr(model);
   if (ni < 0 || n_cams < 1 || n_cams > CAMCAL_RIG_MAX_CAMS || !n_tiles_host || P <= 0) return CAMCAL_E_BADARG;
-  int64_t ev = 0;                                   // evaluation partials: up to 64 per tile (grouped small sets)
-  for (int c = 0; c < n_cams; ++c) {
-    const int64_t nt = n_tiles_host[c] > 0 ? n_tiles_host[c] : 0;
-    ev += (int64_t)MAX_NV * (nt <= GROUP64_MAX_TILES ? nt * 64 : nt <= RIG_GROUP16_MAX_TILES ? nt * 16
-                                                                 : nt <= RIG_GROUP4_MAX_TILES ? nt * 4 : nt);
-  }
-  const int64_t as = (int64_t)n_cams * MAX_NV * MAX_WAVES;                   // chain-rule partials
-  const int64_t gr = (int64_t)RIG_GRAM_MAX_WAVES * RIG_GRAM_VALS;            // gram partials
-  const int64_t in = (int64_t)n_cams * n_cams * 13 * (MAX_WAVES + 1);        // pair sums
-  int64_t m = ev > as ? ev : as;
-  m = m > gr ? m : gr;
-  m = m > in ? m : in;
-  return m + (int64_t)CAMCAL_RIG_MAX_CAMS * MAX_NV + 256;                    // + reduced values / small records
+  return rig_work_len(n_cams, n_tiles_host, P) + (int64_t)RIG_FACTOR_ROWS * P;
 }
 
 int camcal_rig_residuals(const camcal_rig* rig, int b, void* stream) {
@@ -799,8 +823,8 @@ int camcal_rig_eliminate(const camcal_rig* rig, int b, double lam, void* stream)
   const RigLayout L(camcal_n_intr(rig->model), nC);
   const int64_t P = rig->P;
   const dim3 gr((unsigned)((P + TPB - 1) / TPB), (unsigned)((L.n + RIG_SCHUR_CHUNK - 1) / RIG_SCHUR_CHUNK)), bl(TPB);
-  if (L.NI == 9) hipLaunchKernelGGL(k_rig_pose_schur<15>, gr, bl, 0, s, nC, P, rig->Vp[b], rig->gp[b], rig->Wp[b], lam, rig->Yt, rig->z);
-  else hipLaunchKernelGGL(k_rig_pose_schur<14>, gr, bl, 0, s, nC, P, rig->Vp[b], rig->gp[b], rig->Wp[b], lam, rig->Yt, rig->z);
+  if (L.NI == 9) hipLaunchKernelGGL(k_rig_pose_schur<15>, gr, bl, 0, s, nC, P, rig->Vp[b], rig->gp[b], rig->Wp[b], lam, rig->Yt, rig->z, rig_factor_ptr(rig));
+  else hipLaunchKernelGGL(k_rig_pose_schur<14>, gr, bl, 0, s, nC, P, rig->Vp[b], rig->gp[b], rig->Wp[b], lam, rig->Yt, rig->z, rig_factor_ptr(rig));
   HIP_TRY(hipGetLastError());
   const int nw = rig_gram_waves(P);
   hipLaunchKernelGGL(k_rig_gram, dim3((nw * 5 + WPB - 1) / WPB), bl, 0, s, L.n, P, rig->Yt, rig->z, rig->scratch, nw);
@@ -831,8 +855,9 @@ int camcal_rig_backsub(const camcal_rig* rig, int b, double lam, int out, void* 
   int64_t nb = (P + 16 * WPB - 1) / (16 * WPB);         // 16 poses per wavefront
   if (nb > MAX_WAVES / WPB) nb = MAX_WAVES / WPB;
   hipStream_t s = (hipStream_t)stream;
-  if (L.NI == 9) hipLaunchKernelGGL(k_rig_backsub<15>, dim3((unsigned)nb), dim3(TPB), 0, s, rig->n_cams, P, rig->Vp[b], rig->gp[b], rig->Wp[b], lam, rig->dG, rig->rig_pose[b], rig->rig_pose[out], rig->scratch);
-  else hipLaunchKernelGGL(k_rig_backsub<14>, dim3((unsigned)nb), dim3(TPB), 0, s, rig->n_cams, P, rig->Vp[b], rig->gp[b], rig->Wp[b], lam, rig->dG, rig->rig_pose[b], rig->rig_pose[out], rig->scratch);
+  (void)lam;                                            // the factor of camcal_rig_eliminate(rig, b, lam) is reused
+  hipLaunchKernelGGL(k_rig_backsub, dim3((unsigned)nb), dim3(TPB), 0, s, L.n, P, rig->Yt, rig->z, rig_factor_ptr(rig), rig->dG,
+                     rig->rig_pose[b], rig->rig_pose[out], rig->scratch);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_finalize, dim3(2), dim3(TPB), 0, s, rig->scratch, (int)nb * WPB, rig->rec[out] + L.o_norms);
   HIP_TRY(hipGetLastError());

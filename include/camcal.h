@@ -345,7 +345,10 @@ int camcal_rig_eliminate(const camcal_rig* rig, int b, double lam, void* stream)
  * intr/ext[b] - dG; gstats of rec[out]; NaN step if the matrix is not positive. */
 int camcal_rig_solve(const camcal_rig* rig, int b, const uint8_t* mask_host, double lam, int out, void* stream);
 
-/* d_p = V'^-1 (g_p - Wp^T dG), rig_pose[out] = rig_pose[b] - d_p; norms of rec[out]. */
+/* d_p = V'^-1 (g_p - Wp^T dG) = U^-1 (z_p - Y_p dG), rig_pose[out] = rig_pose[b] - d_p; norms of
+ * rec[out].  Uses Yt, z and the pose factors that camcal_rig_eliminate(rig, b, lam) left in
+ * rig->scratch: call it after that eliminate (and the solve), with nothing but
+ * camcal_rig_solve in between. */
 int camcal_rig_backsub(const camcal_rig* rig, int b, double lam, int out, void* stream);
 
 /* Starting point into buffer 0 from intr[0] (the guesses): per-camera pose initialisation

@@ -228,13 +228,14 @@ void rig_pose_schur(int n_cams, int64_t P, const double* Vp, const double* gp, c
                     double* z) {
   for (int64_t p = 0; p < P; ++p) {
     double U[21], g[6];
-    const bool ok = rig_pose_factor<G>(n_cams, Vp, gp, P, p, lam, U, g);
-    if (ok) chol6_fwd(U, g);
+    double id[6];
+    const bool ok = rig_pose_factor<G>(n_cams, Vp, gp, P, p, lam, U, g, id);
+    if (ok) chol6_fwd(U, id, g);
     for (int k = 0; k < 6; ++k) z[k * P + p] = ok ? g[k] : 0.0;
     for (int v = 0; v < n_cams * G; ++v) {
       double y[6];
       for (int k = 0; k < 6; ++k) y[k] = Wp[((int64_t)v * 6 + k) * P + p];
-      if (ok) chol6_fwd(U, y);
+      if (ok) chol6_fwd(U, id, y);
       for (int k = 0; k < 6; ++k) Yt[((int64_t)v * 6 + k) * P + p] = ok ? y[k] : 0.0;
     }
   }
@@ -246,13 +247,14 @@ void rig_backsub(int n_cams, int64_t P, const double* Vp, const double* gp, cons
   double a0 = 0, a1 = 0;
   for (int64_t p = 0; p < P; ++p) {
     double U[21], rhs[6];
-    const bool ok = rig_pose_factor<G>(n_cams, Vp, gp, P, p, lam, U, rhs);
+    double id[6];
+    const bool ok = rig_pose_factor<G>(n_cams, Vp, gp, P, p, lam, U, rhs, id);
     if (ok) {
       for (int c = 0; c < n_cams; ++c)
         for (int a = 0; a < G; ++a)
           for (int k = 0; k < 6; ++k) rhs[k] -= Wp[(((int64_t)c * G + a) * 6 + k) * P + p] * dG[c * G + a];
-      chol6_fwd(U, rhs);
-      chol6_bwd(U, rhs);
+      chol6_fwd(U, id, rhs);
+      chol6_bwd(U, id, rhs);
     }
     for (int k = 0; k < 6; ++k) {
       const double prev = pin[k * P + p], d = ok ? rhs[k] : 0.0;
