@@ -160,7 +160,7 @@ class Engine:
         NI = self.NI
         sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
                      W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, norms=2, dK=16,
-                     stats=8, view_cost=S)        # norms right behind glob1: one all-reduce for a trial point
+                     stats=8, view_cost=S, ints=S)   # norms right behind glob1: one all-reduce for a trial point
         pool = torch.zeros(sum(sizes.values()), **f64)
         part, off = {}, 0
         for k, n_k in sizes.items():
@@ -169,8 +169,7 @@ class Engine:
         self._pool = pool
         self.intr = [part["intr0"], part["intr1"]]
         self.pose = [part["pose0"].view(6, S), part["pose1"].view(6, S)]
-        self.pose[0][5] = 1.0
-        self.pose[1][5] = 1.0
+        pool[32:32 + 12 * S].view(2, 6, S)[:, 5] = 1.0      # both pose buffers: identity-like default, one fill
         # pose blocks are double-buffered (current / trial point), W is not
         self.Vs = [part["V0"].view(21, S), part["V1"].view(21, S)]
         self.gs = [part["g0"].view(6, S), part["g1"].view(6, S)]
@@ -186,7 +185,7 @@ class Engine:
         self.view_cost = part["view_cost"]
         # partial sums: every entry a launch reads was written by that launch
         self.scratch = torch.empty(int(self.lib.camcal_scratch_len(self.model, n_tiles)), **f64)
-        ints = torch.zeros(2 * S, dtype=torch.int32, device=dev)
+        ints = part["ints"].view(torch.int32)                # 2 S int32 in the same allocation
         self.status, self.iters = ints[:S], ints[S:]
 
     # -- plumbing ------------------------------------------------------------

@@ -76,7 +76,7 @@ class RigEngine:
         self.NX = self.NI * 6 + 27
         self.n_obs = sum(e.n_obs for e in self.E)
         f64 = dict(dtype=torch.float64, device=dev)
-        self.slot_pose = []
+        sps = []
         seen = np.zeros(self.P, dtype=bool)
         for e, c in zip(self.E, cams):
             pi = np.asarray(c["pose_idx"], dtype=np.int64)
@@ -88,34 +88,51 @@ class RigEngine:
             sv = e.layout["slot_view"]
             sp = np.full(e.S, -1, dtype=np.int32)
             sp[sv >= 0] = pi[sv[sv >= 0]]
-            self.slot_pose.append(torch.from_numpy(sp).to(dev))
+            sps.append(sp)
         self.seen = seen
+        t_sp = torch.from_numpy(np.concatenate(sps)).to(dev)          # one upload for all cameras
+        self.slot_pose, o = [], 0
+        for e in self.E:
+            self.slot_pose.append(t_sp[o:o + e.S])
+            o += e.S
         nC, P, G, n = self.n_cams, self.P, self.G, self.nG
-        self.intr = [torch.zeros(nC, 16, **f64), torch.zeros(nC, 16, **f64)]
-        self.ext = [torch.zeros(nC, 6, **f64), torch.zeros(nC, 6, **f64)]
-        self.rig_pose = [torch.zeros(6, P, **f64), torch.zeros(6, P, **f64)]
-        for b in range(2):
-            self.rig_pose[b][5] = 1.0
-        self.Vp = [torch.zeros(nC, 21, P, **f64) for _ in range(2)]
-        self.gp = [torch.zeros(nC, 6, P, **f64) for _ in range(2)]
-        self.Wp = [torch.zeros(nC, G * 6, P, **f64) for _ in range(2)]
         # rec[b] = [per-camera records | cost | norms | gstats | C | d] (include/camcal.h)
         self.rec_len = nC * (self.NV + self.NX)
         self.o_cost, self.o_norms, self.o_gstats = self.rec_len, self.rec_len + 1, self.rec_len + 3
         self.o_C = self.rec_len + 5
         total = int(self.lib.camcal_rig_rec_len(self.model, nC))
         assert total == self.o_C + n * n + n
-        self.rec = [torch.zeros(total, **f64) for _ in range(2)]
-        self.Yt = torch.zeros(n * 6, P, **f64)
-        self.z = torch.zeros(6, P, **f64)
-        self.dG = torch.zeros(64, **f64)
         nt = np.asarray([e.layout["n_tiles"] for e in self.E], dtype=np.int32)
-        self.scratch = torch.zeros(int(self.lib.camcal_rig_scratch_len(self.model, nC, nt.ctypes.data, P)), **f64)
+        n_scratch = int(self.lib.camcal_rig_scratch_len(self.model, nC, nt.ctypes.data, P))
+        # one zeroed allocation, carved up: the pose blocks of (camera, pose) pairs without a
+        # view must be zero, everything else is written before it is read
+        sizes = [("intr0", nC * 16), ("intr1", nC * 16), ("ext0", nC * 6), ("ext1", nC * 6), ("rec0", total), ("rec1", total),
+                 ("dG", 64), ("pose0", 6 * P), ("pose1", 6 * P), ("z", 6 * P),
+                 ("Vp0", nC * 21 * P), ("Vp1", nC * 21 * P), ("gp0", nC * 6 * P), ("gp1", nC * 6 * P),
+                 ("Wp0", nC * G * 6 * P), ("Wp1", nC * G * 6 * P), ("Yt", n * 6 * P), ("scratch", n_scratch)]
+        pool = torch.zeros(sum(k for _, k in sizes), **f64)
+        part, off = {}, 0
+        for name, k in sizes:
+            part[name] = pool[off:off + k]
+            off += k
+        self._pool = pool
+        self.intr = [part["intr0"].view(nC, 16), part["intr1"].view(nC, 16)]
+        self.ext = [part["ext0"].view(nC, 6), part["ext1"].view(nC, 6)]
+        self.rig_pose = [part["pose0"].view(6, P), part["pose1"].view(6, P)]
+        pool[part["pose0"].storage_offset():part["pose1"].storage_offset() + 6 * P].view(2, 6, P)[:, 5] = 1.0
+        self.Vp = [part["Vp0"].view(nC, 21, P), part["Vp1"].view(nC, 21, P)]
+        self.gp = [part["gp0"].view(nC, 6, P), part["gp1"].view(nC, 6, P)]
+        self.Wp = [part["Wp0"].view(nC, G * 6, P), part["Wp1"].view(nC, G * 6, P)]
+        self.rec = [part["rec0"], part["rec1"]]
+        self.Yt = part["Yt"].view(n * 6, P)
+        self.z = part["z"].view(6, P)
+        self.dG = part["dG"]
+        self.scratch = part["scratch"]
         S_all = sum(e.S for e in self.E)
-        self.status = torch.zeros(S_all, dtype=torch.int32, device=dev)
-        self.pose_slot = [torch.full((P,), -1, dtype=torch.int32, device=dev) for _ in range(nC)]
-        self._tri_i = torch.from_numpy(_tri_index(self.NI)).to(dev)
-        self._tri_6 = torch.from_numpy(_tri_index(6)).to(dev)
+        ints = torch.zeros(S_all + nC * P, dtype=torch.int32, device=dev)     # pose_slot: filled by camcal_rig_init
+        self.status = ints[:S_all]
+        self.pose_slot = [ints[S_all + c * P:S_all + (c + 1) * P] for c in range(nC)]
+        self._tri = None
         self._fill_struct()
 
     def _fill_struct(self):
@@ -196,16 +213,18 @@ class RigEngine:
         """(M, rhs) over the n_cams*(NI+6) globals, diag(M) damped like CvLevMarq."""
         NI, G, nC = self.NI, self.G, self.n_cams
         nt = NI * (NI + 1) // 2
+        if self._tri is None:
+            self._tri = (torch.from_numpy(_tri_index(NI)).to(self.device), torch.from_numpy(_tri_index(6)).to(self.device))
         M = torch.zeros(self.nG, self.nG, dtype=torch.float64, device=self.device)
         rhs = torch.zeros(self.nG, dtype=torch.float64, device=self.device)
         for c in range(nC):
             glob, rx = self.cam_rec(b, c)
             o = c * G
-            M[o:o + NI, o:o + NI] = glob[:nt][self._tri_i]
+            M[o:o + NI, o:o + NI] = glob[:nt][self._tri[0]]
             Uie = rx[:NI * 6].view(NI, 6)
             M[o:o + NI, o + NI:o + G] = Uie
             M[o + NI:o + G, o:o + NI] = Uie.t()
-            M[o + NI:o + G, o + NI:o + G] = rx[NI * 6:NI * 6 + 21][self._tri_6]
+            M[o + NI:o + G, o + NI:o + G] = rx[NI * 6:NI * 6 + 21][self._tri[1]]
             rhs[o:o + NI] = glob[nt:nt + NI]
             rhs[o + NI:o + G] = rx[NI * 6 + 21:]
         M.diagonal().mul_(1.0 + lam)
@@ -235,7 +254,7 @@ class RigEngine:
 
     def _comm_pools(self):
         """Tensors a torch.distributed callback communicator may be asked to reduce parts of."""
-        return [self.rec[0], self.rec[1], self.scratch]
+        return [self._pool]
 
 
 def lm_rig(R, free, max_iter, eps, comm=None, log=None):
@@ -376,7 +395,7 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
     if not ctype & 2:
         eps = DBL_EPSILON
     log = [] if (_info is not None and _info.get("log") is True) else None
-    init_state = R.get_params(0) if _info is not None else None
+    init_state = R.get_params(0) if (_info is not None and _info.get("init") is True) else None
     err, iters = lm_rig(R, free.reshape(-1), maxc, eps, comm=comm, log=log)
     n_total = comm.total(R.n_obs, dev)
     rms = float(np.sqrt(err / n_total))

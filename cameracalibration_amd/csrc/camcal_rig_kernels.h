@@ -335,17 +335,22 @@ __global__ __launch_bounds__(TPB) void k_rig_gram(int n, int64_t P, const double
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_rig_gram_finalize(int n, int n_waves, const double* __restrict__ part,
-                                                           double* __restrict__ Cm, double* __restrict__ d) {
-  __shared__ double sh[WPB][64];
+constexpr int RIG_GF_WAVES = 16;                   // wavefronts of a k_rig_gram_finalize block
+__global__ __launch_bounds__(RIG_GF_WAVES * 64) void k_rig_gram_finalize(int n, int n_waves, const double* __restrict__ part,
+                                                                         double* __restrict__ Cm, double* __restrict__ d) {
+  __shared__ double sh[RIG_GF_WAVES][64];
   const int row = blockIdx.x;                       // (tile index, register): 64 values, one per lane
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  // 8 partials per wavefront at RIG_GRAM_MAX_WAVES groups, all loads in flight; fixed order
   double s = 0.0;
-  for (int w = q; w < n_waves; w += WPB) s += part[(int64_t)w * RIG_GRAM_VALS + row * 64 + lane];
+#pragma unroll 8
+  for (int w = q; w < n_waves; w += RIG_GF_WAVES) s += part[(int64_t)w * RIG_GRAM_VALS + row * 64 + lane];
   sh[q][lane] = s;
   __syncthreads();
   if (q != 0) return;
-  s = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < RIG_GF_WAVES; ++k) s += sh[k][lane];
   const int r = row & 3, idx = row >> 2;
   int ti = 0, tj = 0, k = 0;
   for (int a = 0; a < 4; ++a)
@@ -535,9 +540,13 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
   for (int k = 0; k < n; ++k) {
     const int kb = k >> 4;                           // uniform
     if (tx == (k & 15)) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-        Lc[k * RIG_LD + ty + 16 * a] = kb == 0 ? v[a][0] : kb == 1 ? v[a][1] : kb == 2 ? v[a][2] : v[a][3];
+      double* dst = Lc + k * RIG_LD + ty;
+      switch (kb) {                                  // uniform: one scalar branch, no selects
+        case 0: dst[0] = v[0][0]; dst[16] = v[1][0]; dst[32] = v[2][0]; dst[48] = v[3][0]; break;
+        case 1: dst[0] = v[0][1]; dst[16] = v[1][1]; dst[32] = v[2][1]; dst[48] = v[3][1]; break;
+        case 2: dst[0] = v[0][2]; dst[16] = v[1][2]; dst[32] = v[2][2]; dst[48] = v[3][2]; break;
+        default: dst[0] = v[0][3]; dst[16] = v[1][3]; dst[32] = v[2][3]; dst[48] = v[3][3]; break;
+      }
     }
     __syncthreads();
     const double p = Lc[k * RIG_LD + k];
@@ -556,15 +565,12 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
       aik[a] = Lc[k * RIG_LD + ty + 16 * a] * rp;
       ajk[a] = Lc[k * RIG_LD + tx + 16 * a];
     }
+    // all ten blocks every step: finished ones take garbage that nothing reads, which is
+    // cheaper than a scalar branch per block
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (16 * a + 15 <= k) continue;                // uniform: block row finished
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b <= a; ++b) {
-        if (16 * b + 15 <= k) continue;
-        v[a][b] = fma(-aik[a], ajk[b], v[a][b]);
-      }
-    }
+      for (int b = 0; b <= a; ++b) v[a][b] = fma(-aik[a], ajk[b], v[a][b]);
   }
   __syncthreads();
   if (tid >= 64) return;
@@ -829,7 +835,7 @@ int camcal_rig_eliminate(const camcal_rig* rig, int b, double lam, void* stream)
   const int nw = rig_gram_waves(P);
   hipLaunchKernelGGL(k_rig_gram, dim3((nw * 5 + WPB - 1) / WPB), bl, 0, s, L.n, P, rig->Yt, rig->z, rig->scratch, nw);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_rig_gram_finalize, dim3(RIG_GRAM_TILES * 4), bl, 0, s, L.n, nw, rig->scratch,
+  hipLaunchKernelGGL(k_rig_gram_finalize, dim3(RIG_GRAM_TILES * 4), dim3(RIG_GF_WAVES * 64), 0, s, L.n, nw, rig->scratch,
                      rig->rec[b] + L.o_C, rig->rec[b] + L.o_d);
   HIP_TRY(hipGetLastError());
   return 0;
