@@ -490,8 +490,7 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
                                                            double* __restrict__ intr_out, double* __restrict__ ext_out,
                                                            double* __restrict__ dG, double* __restrict__ stats) {
   __shared__ double Lc[RIG_MAXN * RIG_LD];        // Lc[k * RIG_LD + i] = a_ik as published in step k
-  __shared__ double sc[RIG_MAXN], rpv[RIG_MAXN];
-  __shared__ int okf;
+  __shared__ double sc[RIG_MAXN];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int n = n_cams * (NI + 6);
   double v[4][4];
@@ -523,7 +522,7 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
       if (i < n) sc[i] = dii > 0.0 ? 1.0 / sqrt(dii) : 1.0;
     }
   }
-  if (tid == 0) { sc[n] = 1.0; okf = 1; }
+  if (tid == 0) sc[n] = 1.0;
   __syncthreads();
   {
     double si[4], sj[4];
@@ -537,6 +536,8 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
 #pragma unroll
       for (int b = 0; b < 4; ++b) v[a][b] *= si[a] * sj[b];
   }
+  bool ok = true;
+  double rpl = 0.0;
   for (int k = 0; k < n; ++k) {
     const int kb = k >> 4;                           // uniform
     if (tx == (k & 15)) {
@@ -555,10 +556,8 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
     const double r0 = __builtin_amdgcn_rcp(good ? p : 1.0);
     const double er = fma(-p, r0, 1.0);
     const double rp = good ? fma(r0, fma(er, er, er), r0) : 0.0;
-    if (tid == 0) {
-      rpv[k] = rp;
-      if (!good) okf = 0;
-    }
+    ok = ok && good;
+    rpl = tid == k ? rp : rpl;                       // lane k of the first wavefront keeps 1 / p_k
     double aik[4], ajk[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -578,7 +577,6 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
   // z_j = y_j / p_j and its column pre-divided, so a step is one broadcast and one fma:
   //   x_k = z_k,   z_j -= (a_kj / p_j) x_k   (j < k).
   const int lane = tid;
-  const double rpl = lane < n ? rpv[lane] : 0.0;
   double col[RIG_MAXN];
 #pragma unroll
   for (int k = 0; k < RIG_MAXN; ++k) col[k] = (k < n && lane < k) ? Lc[lane * RIG_LD + k] * rpl : 0.0;
@@ -593,7 +591,6 @@ __global__ __launch_bounds__(TPB) void k_rig_solve_reduced(int NI, int n_cams, c
   }
   // rig_solve_finish, one parameter per lane: out = in - dG, stats = [||dG||^2, ||globals_in||^2];
   // a failed factorisation gives NaN so that the LM driver rejects the step
-  const bool ok = okf != 0;
   double s0 = 0.0, s1 = 0.0;
   if (lane < n) {
     const int G = NI + 6, c = lane / G, a = lane - c * G;
