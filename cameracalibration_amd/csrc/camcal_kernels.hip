@@ -463,7 +463,7 @@ __device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, con
   }
   GroupAllReduce<21, G / 2>::run(V, threadIdx.x & 63);
   GroupAllReduce<6, G / 2>::run(g, threadIdx.x & 63);
-  return pose_gn_update(V, g, pose, change);       // every lane of the group holds the same sums
+  return pose_gn_update<MODEL == FISHEYE>(V, g, pose, change);       // every lane of the group holds the same sums
 }
 
 template <int MODEL, bool PLANAR>

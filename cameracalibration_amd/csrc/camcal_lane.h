@@ -198,19 +198,118 @@ CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double
 // ---------------------------------------------------------------------------
 // K4: per-view pose refinement with fixed intrinsics (Gauss-Newton), the
 // restatement of cv::internal::ComputeExtrinsicRefine: x += -(J^T J)^-1 J^T e,
-// stop when ||d|| / ||x + d|| <= tol or after max_iter steps.  Returns the
-// number of steps taken.  (cv2's cond(J) > 1e6 early-out is not evaluated.)
+// stop when ||d|| / ||x + d|| <= tol, when cond(J) > 1e6 (fisheye: the view keeps
+// the pose it has, as in cv2) or after max_iter steps.  Returns the number of steps taken.
+
+// Eigenvalues of a symmetric 6x6 (packed upper, destroyed): cyclic Jacobi, 6 sweeps.
+// Only the extreme ones are wanted, to ~1e-16 of the largest.
+CC_HD void sym6_eig_range(double A[21], double& lo, double& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int sweep = 0; sweep < 6; ++sweep) {
+    CC_UNROLL
+    for (int p = 0; p < 5; ++p)
+      CC_UNROLL
+      for (int q = p + 1; q < 6; ++q) {
+        const double apq = A[tri(6, p, q)];
+        const double app = A[tri(6, p, p)], aqq = A[tri(6, q, q)];
+        // a rotation by (near) zero where the entry is already negligible
+        const bool live = fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * (fabs(app) + fabs(aqq));
+        const double th = live ? (aqq - app) / (2.0 * apq) : 0.0;
+        double t = 1.0 / (fabs(th) + sqrt(th * th + 1.0));
+        t = th < 0.0 ? -t : t;
+        t = live ? t : 0.0;
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        A[tri(6, p, p)] = app - t * apq;
+        A[tri(6, q, q)] = aqq + t * apq;
+        A[tri(6, p, q)] = live ? 0.0 : apq;
+        CC_UNROLL
+        for (int k = 0; k < 6; ++k) {
+          if (k == p || k == q) continue;
+          const int ikp = k < p ? tri(6, k, p) : tri(6, p, k), ikq = k < q ? tri(6, k, q) : tri(6, q, k);
+          const double akp = A[ikp], akq = A[ikq];
+          A[ikp] = c * akp - sn * akq;
+          A[ikq] = sn * akp + c * akq;
+        }
+      }
+  }
+  lo = A[tri(6, 0, 0)];
+  hi = lo;
+  CC_UNROLL
+  for (int i = 1; i < 6; ++i) {
+    lo = fmin(lo, A[tri(6, i, i)]);
+    hi = fmax(hi, A[tri(6, i, i)]);
+  }
+}
+
+// cv2's guard of ComputeExtrinsicRefine: cond(J) = sqrt(lmax / lmin of J^T J) > 1e6.
+// U: Cholesky factor of J^T J (U^T U), inv_diag = 1 / U_ii, tr / dmax: trace and largest
+// diagonal entry of J^T J.  Two bounds decide almost every view from the inverse factor,
+//   dmax * max diag((J^T J)^-1)  <=  lmax / lmin  <=  tr * tr((J^T J)^-1),
+// and only a view whose ratio lies within a factor 36 of the threshold pays for eigenvalues.
+CC_HD bool pose_cond_tripped(const double U[21], const double inv_diag[6], double tr, double dmax) {
+  const double thresh2 = 1e12;
+  double Ui[21];                                   // U^-1, upper
+  CC_UNROLL
+  for (int j = 0; j < 6; ++j) {
+    Ui[tri(6, j, j)] = inv_diag[j];
+    CC_UNROLL
+    for (int i = j - 1; i >= 0; --i) {
+      double sm = 0.0;
+      CC_UNROLL
+      for (int k = i + 1; k <= j; ++k) sm = fma(U[tri(6, i, k)], Ui[tri(6, k, j)], sm);
+      Ui[tri(6, i, j)] = -sm * inv_diag[i];
+    }
+  }
+  double tinv = 0.0, dinv = 0.0;
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i) {
+    double row = 0.0;
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) row = fma(Ui[tri(6, i, j)], Ui[tri(6, i, j)], row);
+    tinv += row;
+    dinv = fmax(dinv, row);
+  }
+  if (dmax * dinv > thresh2) return true;
+  if (tr * tinv <= thresh2) return false;
+  double A[21];                                    // J^T J back from its factor
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i)
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) {
+      double sm = 0.0;
+      CC_UNROLL
+      for (int k = 0; k <= i; ++k) sm = fma(U[tri(6, k, i)], U[tri(6, k, j)], sm);
+      A[tri(6, i, j)] = sm;
+    }
+  double lo, hi;
+  sym6_eig_range(A, lo, hi);
+  return !(lo > 0.0) || hi > thresh2 * lo;
+}
+
 // finish of one Gauss-Newton pose step from the local-frame sums V, g: map to
-// Rodrigues coordinates, solve, update; returns false on a non-positive pivot
+// Rodrigues coordinates, solve, update; returns false (pose untouched) on a non-positive
+// pivot or, with COND, when cv2's condition-number guard trips
+template <bool COND>
 CC_HD bool pose_gn_update(double V[21], double g[6], double pose[6], double& change) {
   double Jl[9];
   left_jacobian(pose, Jl);
   vg_to_rodrigues_frame(Jl, V, g);
+  double tr = 0.0, dmax = 0.0;
+  if (COND) {
+    CC_UNROLL
+    for (int i = 0; i < 6; ++i) {
+      tr += V[tri(6, i, i)];
+      dmax = fmax(dmax, V[tri(6, i, i)]);
+    }
+  }
   double id[6];
   const bool ok = chol6(V, id);
+  if (!ok) return false;
+  if (COND && pose_cond_tripped(V, id, tr, dmax)) return false;
   chol6_fwd(V, id, g);
   chol6_bwd(V, id, g);
-  if (!ok) return false;
   double d2 = 0.0, x2 = 0.0;
   CC_UNROLL
   for (int i = 0; i < 6; ++i) {
@@ -245,7 +344,7 @@ CC_HD bool lane_pose_gn_step(const LaneTile& tv, const double* intr, double pose
     pose_row(Yr, p.gv, jv);
     accumulate_vg(V, g, ju, jv, eu, ev);
   });
-  return pose_gn_update(V, g, pose, change);
+  return pose_gn_update<MODEL == FISHEYE>(V, g, pose, change);
 }
 
 template <int MODEL, bool PLANAR>

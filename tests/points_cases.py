@@ -366,3 +366,52 @@ def case_session_growing_lists():
 
 
 ALL.append(case_session_growing_lists)
+
+
+def case_condition_guard():
+    """cv2's ComputeExtrinsicRefine leaves a view alone once cond(J) > 1e6 (fisheye.cpp,
+    thresh_cond of cv::fisheye::calibrate).  Views far from the camera trip it (the
+    translation along the axis is barely observable); the refinement must stop for exactly
+    those views, with the pose it had and the step count of the oracle, and go on for the
+    rest -- under every lane mapping (the group kernels share the guard)."""
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    P = synth.config("C2", n_views=96, seed=5)
+    K4, D = synth.FISHEYE_TRUE_K, np.array(synth.FISHEYE_TRUE_D)
+    vp = P.view_ptr.cpu().numpy() if hasattr(P.view_ptr, "cpu") else np.asarray(P.view_ptr)
+    obj = P.obj.cpu().numpy().copy() if hasattr(P.obj, "cpu") else np.array(P.obj)
+    img = P.img.cpu().numpy().copy() if hasattr(P.img, "cpu") else np.array(P.img)
+    start = P.poses_true.cpu().numpy().copy() if hasattr(P.poses_true, "cpu") else np.array(P.poses_true)
+    rng = np.random.default_rng(11)
+    far = np.arange(0, 96, 7)                       # 14 views moved far away, one of them only moderately
+    for k, v in enumerate(far):
+        z = 3.0e4 if k == 0 else 10.0 ** rng.uniform(5.3, 6.5)
+        pose = np.array([0.1, -0.15, 0.2, 30.0, -20.0, z])
+        a, b = vp[v], vp[v + 1]
+        uv = M.project_fisheye(obj[a:b].astype(np.float64), pose[:3], pose[3:], K4, D)
+        img[a:b] = (uv + rng.normal(0.0, 0.05, uv.shape)).astype(np.float32)
+        start[v] = pose + np.array([1e-3, -1e-3, 2e-3, 1.0, -1.0, 1e-3 * z])
+    g = np.concatenate([K4, D])
+    objs = [obj[vp[i]:vp[i + 1]].reshape(-1, 1, 3) for i in range(96)]
+    imgs = [img[vp[i]:vp[i + 1]].reshape(-1, 1, 2) for i in range(96)]
+    views = O.Views(objs, imgs)
+    want, iters = O.refine_poses_fisheye_batched(views, start, g)
+    tripped = np.array([O.extrinsic_refine_fisheye(objs[v].reshape(-1, 3).astype(np.float64),
+                                                   imgs[v].reshape(-1, 2).astype(np.float64), start[v], g)[2]
+                        for v in range(96)])
+    assert 8 <= int(tripped.sum()) < 96 and not tripped[far[0]]      # the guard matters, and not for every far view
+    for lpv in (1, 16, 64):
+        E = Engine(_lib.FISHEYE, vp, obj, img, dev, lib=lib, lanes_per_view=lpv)
+        E.set_intr(0, g)
+        E.set_poses(0, start)
+        E.pose_refine(0, 0, 20, 1e-10)
+        got, it = E.get_poses(0), E.slots_to_views(E.iters)
+        assert np.array_equal(it[tripped], iters[tripped])           # stopped where cv2 stops
+        stopped0 = tripped & (iters == 0)
+        assert stopped0.any() and np.array_equal(got[stopped0], start[stopped0])   # untouched poses
+        assert np.allclose(got, want, rtol=1e-8, atol=1e-7)
+        assert (it == iters).mean() > 0.95
+
+
+ALL.append(case_condition_guard)
