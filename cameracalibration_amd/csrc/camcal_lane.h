@@ -250,26 +250,28 @@ CC_HD void sym6_eig_range(double A[21], double& lo, double& hi) {
 // and only a view whose ratio lies within a factor 36 of the threshold pays for eigenvalues.
 CC_HD bool pose_cond_tripped(const double U[21], const double inv_diag[6], double tr, double dmax) {
   const double thresh2 = 1e12;
-  double Ui[21];                                   // U^-1, upper
+  // U^-1 column by column (a column needs only itself), squared into the row sums
+  // rs[i] = sum_j (U^-1)_ij^2 = ((J^T J)^-1)_ii
+  double rs[6] = {0, 0, 0, 0, 0, 0};
   CC_UNROLL
   for (int j = 0; j < 6; ++j) {
-    Ui[tri(6, j, j)] = inv_diag[j];
+    double col[6];
+    col[j] = inv_diag[j];
     CC_UNROLL
     for (int i = j - 1; i >= 0; --i) {
       double sm = 0.0;
       CC_UNROLL
-      for (int k = i + 1; k <= j; ++k) sm = fma(U[tri(6, i, k)], Ui[tri(6, k, j)], sm);
-      Ui[tri(6, i, j)] = -sm * inv_diag[i];
+      for (int k = i + 1; k <= j; ++k) sm = fma(U[tri(6, i, k)], col[k], sm);
+      col[i] = -sm * inv_diag[i];
     }
+    CC_UNROLL
+    for (int i = 0; i <= j; ++i) rs[i] = fma(col[i], col[i], rs[i]);
   }
   double tinv = 0.0, dinv = 0.0;
   CC_UNROLL
   for (int i = 0; i < 6; ++i) {
-    double row = 0.0;
-    CC_UNROLL
-    for (int j = i; j < 6; ++j) row = fma(Ui[tri(6, i, j)], Ui[tri(6, i, j)], row);
-    tinv += row;
-    dinv = fmax(dinv, row);
+    tinv += rs[i];
+    dinv = fmax(dinv, rs[i]);
   }
   if (dmax * dinv > thresh2) return true;
   if (tr * tinv <= thresh2) return false;
