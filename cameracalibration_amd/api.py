@@ -94,11 +94,11 @@ def _set_test_backend(lib, device):
     _test_backend = None if lib is None else (lib, torch.device(device))
 
 
-def _resolve(lib_override=None, device_override=None):
+def _resolve():
     """(lib or None for the HIP build, device) of a call."""
-    if lib_override is None and device_override is None and _test_backend is not None:
+    if _test_backend is not None:
         return _test_backend
-    return lib_override, (device_override if device_override is not None else _device())
+    return None, _device()
 
 
 def _gather_views(object_points, image_points, min_points=4):
@@ -272,7 +272,7 @@ def _solve_pinhole(E, dev, D, mask, maxc, eps, comm, _info, cameraMatrix, distCo
 
 def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs=None,
                     tvecs=None, flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON),
-                    *, _lib_override=None, _device_override=None, _comm=None, _info=None):
+                    *, _comm=None, _info=None):
     """``cv2.calibrateCamera`` on the MI355X (5-coefficient pinhole model).
 
     Supported: ``CALIB_USE_INTRINSIC_GUESS`` (required -- the only mode the
@@ -285,14 +285,14 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     ``iters``, ``engine`` and ``log`` (the per-iteration records, collected only
     when the dict holds ``log=True``: asking for them keeps the loop in
     solver.py instead of the library); ``_comm`` -- a solver.Comm for a
-    multi-rank solve; ``_lib_override`` / ``_device_override`` -- the tests'
-    CPU lane emulator.
+    multi-rank solve.  (The tests' CPU lane emulator comes in through the
+    module's one hook, ``_set_test_backend``, not through the call.)
     """
     flags = int(flags)
     D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
-    _lib_override, dev = _resolve(_lib_override, _device_override)
-    E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=_lib_override)
+    lib, dev = _resolve()
+    E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=lib)
     E.set_intr(0, intr0)
     # cvFindExtrinsicCameraParams2 per view: homography init + iterative refine
     E.pose_init(0, 0)
@@ -356,7 +356,7 @@ def _solve_fisheye(E, dev, mask, flags, criteria, comm, _info, K, D):
 
 def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, tvecs=None, flags=0,
                       criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON),
-                      *, _lib_override=None, _device_override=None, _comm=None, _info=None):
+                      *, _comm=None, _info=None):
     """``cv2.fisheye.calibrate`` on the MI355X (Kannala-Brandt, k1..k4).
 
     Supported flag set: ``CALIB_USE_INTRINSIC_GUESS | CALIB_FIX_SKEW`` (both
@@ -367,8 +367,8 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
     flags = int(flags)
     intr0, mask = _prep_fisheye(K, D, flags)
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
-    _lib_override, dev = _resolve(_lib_override, _device_override)
-    E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=_lib_override)
+    lib, dev = _resolve()
+    E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=lib)
     E.set_intr(0, intr0)
     # CalibrateExtrinsics: InitExtrinsics + ComputeExtrinsicRefine per view
     E.pose_init(0, 0)
@@ -389,17 +389,16 @@ class CalibrationSession:
     -- to the refinement tolerance -- the same numbers as the one-shot functions
     (``tests/test_hostlogic.py::test_session_*``)."""
 
-    def __init__(self, model, *, _lib_override=None, _device_override=None):
+    def __init__(self, model):
         if model not in ("pinhole", "fisheye"):
             raise error("model must be 'pinhole' or 'fisheye'")
         self.model = model
-        self._lib_override, self._device_override = _lib_override, _device_override
         self._E = None
         self._held = []                 # (object array, image array) of every view on the device
 
     def _sync(self, objectPoints, imagePoints):
         """Bring the engine to the given lists; returns the slots of the views added."""
-        lib, dev = _resolve(self._lib_override, self._device_override)
+        lib, dev = _resolve()
         nh = len(self._held)
         same = (self._E is not None and len(objectPoints) >= nh and len(imagePoints) == len(objectPoints) and
                 all(objectPoints[j] is self._held[j][0] and imagePoints[j] is self._held[j][1] for j in range(nh)))

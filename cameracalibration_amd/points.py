@@ -35,8 +35,8 @@ CV_32FC1 = 5
 SOLVEPNP_ITERATIVE = 0
 
 
-def _ctx(lib_override, device_override):
-    lib, dev = _resolve(lib_override, device_override)
+def _ctx():
+    lib, dev = _resolve()
     lib = lib if lib is not None else _lib.load()
     if dev.type != "cuda" and not lib.is_emulator:
         raise _lib.CamcalError("the HIP library needs a cuda (ROCm) device; there is no CPU path")
@@ -83,8 +83,8 @@ def _to_dev(a, dev):
 
 
 # --- N1: projection and the reprojection error ---------------------------------
-def _project(model, objectPoints, rvec, tvec, K, D, lib_override, device_override):
-    lib, dev = _ctx(lib_override, device_override)
+def _project(model, objectPoints, rvec, tvec, K, D):
+    lib, dev = _ctx()
     op = np.asarray(objectPoints)
     if op.size % 3:
         raise error("objectPoints must be Nx3")
@@ -105,19 +105,17 @@ def _project(model, objectPoints, rvec, tvec, K, D, lib_override, device_overrid
 
 
 def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, imagePoints=None, jacobian=None,
-                  aspectRatio=0, *, _lib_override=None, _device_override=None):
+                  aspectRatio=0):
     """``cv2.projectPoints`` -> (imagePoints (n,1,2) in the depth of objectPoints, None);
     the Jacobian output is not provided (the reference discards it)."""
-    return _project(_lib.PINHOLE, objectPoints, rvec, tvec, cameraMatrix, distCoeffs, _lib_override,
-                    _device_override), None
+    return _project(_lib.PINHOLE, objectPoints, rvec, tvec, cameraMatrix, distCoeffs), None
 
 
-def fisheye_projectPoints(objectPoints, rvec, tvec, K, D, imagePoints=None, alpha=0, jacobian=None, *,
-                          _lib_override=None, _device_override=None):
+def fisheye_projectPoints(objectPoints, rvec, tvec, K, D, imagePoints=None, alpha=0, jacobian=None):
     """``cv2.fisheye.projectPoints`` -> (imagePoints, None)."""
     if alpha != 0:
         raise error("a non-zero skew is not supported")
-    return _project(_lib.FISHEYE, objectPoints, rvec, tvec, K, D, _lib_override, _device_override), None
+    return _project(_lib.FISHEYE, objectPoints, rvec, tvec, K, D), None
 
 
 def norm(src1, src2=None, normType=NORM_L2):
@@ -139,11 +137,10 @@ def checkRange(a):
     return bool(np.all(np.isfinite(np.asarray(a, dtype=np.float64))))
 
 
-def reproj_errors(model, objectPoints, imagePoints, rvecs, tvecs, K, D, f32_round=True, *,
-                  _lib_override=None, _device_override=None):
+def reproj_errors(model, objectPoints, imagePoints, rvecs, tvecs, K, D, f32_round=True):
     """The per-view acceptance numbers ``norm(project(board_i), corners_i) / n_i``
     of a whole list of views in one launch.  Returns (errors (N,), their mean)."""
-    lib, dev = _resolve(_lib_override, _device_override)
+    lib, dev = _resolve()
     mdl = {"pinhole": _lib.PINHOLE, "fisheye": _lib.FISHEYE}[model] if isinstance(model, str) else int(model)
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints, min_points=1)
     E = Engine(mdl, view_ptr, obj, img, dev, lib=lib)
@@ -159,8 +156,8 @@ def reproj_errors(model, objectPoints, imagePoints, rvecs, tvecs, K, D, f32_roun
 
 
 # --- N3: undistortPoints -----------------------------------------------------------
-def _undistort(model, src, K, D, dst, R, P, lib_override, device_override):
-    lib, dev = _ctx(lib_override, device_override)
+def _undistort(model, src, K, D, dst, R, P):
+    lib, dev = _ctx()
     a = np.asarray(src)
     if a.size % 2:
         raise error("points must be Nx2")
@@ -195,26 +192,23 @@ def _undistort(model, src, K, D, dst, R, P, lib_override, device_override):
     return res
 
 
-def undistortPoints(src, cameraMatrix, distCoeffs, dst=None, R=None, P=None, *, _lib_override=None,
-                    _device_override=None):
+def undistortPoints(src, cameraMatrix, distCoeffs, dst=None, R=None, P=None):
     """``cv2.undistortPoints`` (5 fixed-point sweeps, then R and P)."""
-    return _undistort(_lib.PINHOLE, src, cameraMatrix, distCoeffs, dst, R, P, _lib_override, _device_override)
+    return _undistort(_lib.PINHOLE, src, cameraMatrix, distCoeffs, dst, R, P)
 
 
-def fisheye_undistortPoints(distorted, K, D, undistorted=None, R=None, P=None, *, _lib_override=None,
-                            _device_override=None):
+def fisheye_undistortPoints(distorted, K, D, undistorted=None, R=None, P=None):
     """``cv2.fisheye.undistortPoints`` (Newton on theta; -1e6 where it fails)."""
-    return _undistort(_lib.FISHEYE, distorted, K, D, undistorted, R, P, _lib_override, _device_override)
+    return _undistort(_lib.FISHEYE, distorted, K, D, undistorted, R, P)
 
 
 # --- N2: solvePnP ----------------------------------------------------------------------
-def solvePnP_batch(objectPoints, imagePoints, cameraMatrix, distCoeffs, *, _lib_override=None,
-                   _device_override=None):
+def solvePnP_batch(objectPoints, imagePoints, cameraMatrix, distCoeffs):
     """One planar-target pose per view for a list of views, all on the device
     (homography initialisation + 6-dof refinement on the reprojection error, as
     cv2.solvePnP's SOLVEPNP_ITERATIVE does for planar targets).
     Returns (ok (N,) bool, rvecs (N,3), tvecs (N,3))."""
-    lib, dev = _resolve(_lib_override, _device_override)
+    lib, dev = _resolve()
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
     E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=lib)
     E.set_intr(0, _intr(_lib.PINHOLE, cameraMatrix, distCoeffs))
@@ -226,18 +220,17 @@ def solvePnP_batch(objectPoints, imagePoints, cameraMatrix, distCoeffs, *, _lib_
 
 
 def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None, useExtrinsicGuess=False,
-             flags=SOLVEPNP_ITERATIVE, *, _lib_override=None, _device_override=None):
+             flags=SOLVEPNP_ITERATIVE):
     """``cv2.solvePnP`` (SOLVEPNP_ITERATIVE, planar target) -> (retval, rvec (3,1), tvec (3,1))."""
     if flags != SOLVEPNP_ITERATIVE or useExtrinsicGuess:
         raise error("only SOLVEPNP_ITERATIVE without an extrinsic guess is provided")
-    ok, r, t = solvePnP_batch([objectPoints], [imagePoints], cameraMatrix, distCoeffs,
-                              _lib_override=_lib_override, _device_override=_device_override)
+    ok, r, t = solvePnP_batch([objectPoints], [imagePoints], cameraMatrix, distCoeffs)
     return bool(ok[0]), r[0].reshape(3, 1), t[0].reshape(3, 1)
 
 
 # --- N4: undistort / rectify maps -----------------------------------------------------
-def _rectify_map(model, K, D, R, newK, size, m1type, lib_override, device_override):
-    lib, dev = _ctx(lib_override, device_override)
+def _rectify_map(model, K, D, R, newK, size, m1type):
+    lib, dev = _ctx()
     if m1type not in (CV_16SC2, CV_32FC1):
         raise error("m1type must be CV_16SC2 or CV_32FC1")
     w, h = int(size[0]), int(size[1])
@@ -263,23 +256,20 @@ def _rectify_map(model, K, D, R, newK, size, m1type, lib_override, device_overri
     return a1, (a2 if m1type == CV_32FC1 else a2.view(np.uint16))
 
 
-def initUndistortRectifyMap(cameraMatrix, distCoeffs, R, newCameraMatrix, size, m1type, *, _lib_override=None,
-                            _device_override=None):
+def initUndistortRectifyMap(cameraMatrix, distCoeffs, R, newCameraMatrix, size, m1type):
     """``cv2.initUndistortRectifyMap`` -> (map1, map2)."""
-    return _rectify_map(_lib.PINHOLE, cameraMatrix, distCoeffs, R, newCameraMatrix, size, m1type, _lib_override,
-                        _device_override)
+    return _rectify_map(_lib.PINHOLE, cameraMatrix, distCoeffs, R, newCameraMatrix, size, m1type)
 
 
-def fisheye_initUndistortRectifyMap(K, D, R, P, size, m1type, *, _lib_override=None, _device_override=None):
+def fisheye_initUndistortRectifyMap(K, D, R, P, size, m1type):
     """``cv2.fisheye.initUndistortRectifyMap`` -> (map1, map2)."""
-    return _rectify_map(_lib.FISHEYE, K, D, R, P, size, m1type, _lib_override, _device_override)
+    return _rectify_map(_lib.FISHEYE, K, D, R, P, size, m1type)
 
 
-def remap(src, map1, map2, interpolation=INTER_LINEAR, dst=None, borderMode=BORDER_CONSTANT, borderValue=0, *,
-          _lib_override=None, _device_override=None):
+def remap(src, map1, map2, interpolation=INTER_LINEAR, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
     """``cv2.remap`` for 8-bit images, INTER_LINEAR, BORDER_CONSTANT, with the maps of
     :func:`initUndistortRectifyMap` (float32 pair or CV_16SC2 + CV_16UC1)."""
-    lib, dev = _ctx(_lib_override, _device_override)
+    lib, dev = _ctx()
     if interpolation != INTER_LINEAR or borderMode != BORDER_CONSTANT:
         raise error("only INTER_LINEAR with BORDER_CONSTANT is provided")
     img = np.asarray(src)

@@ -346,7 +346,7 @@ def _gather_rig(object_points, image_points):
 
 def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoeffs, model="fisheye",
                   fix_intrinsics=None, criteria=(3, 30, 1e-9), *, cams=None, n_poses=None,
-                  _lib_override=None, _device_override=None, _comm=None, _info=None, _init=None):
+                  _comm=None, _info=None, _init=None):
     """Joint calibration of a camera rig observing shared board poses.
 
     objectPoints[c][p] / imagePoints[c][p]: (n,1,3) / (n,1,2) float32 arrays as
@@ -374,8 +374,8 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
         if K.shape != (3, 3) or D.size != nd:
             raise ValueError("cameraMatrix must be 3x3 and distCoeffs hold %d coefficients" % nd)
         intr0[c] = np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], D])
-    _lib_override, dev = _resolve(_lib_override, _device_override)
-    R = RigEngine(mdl, cams, n_poses, dev, lib=_lib_override)
+    lib, dev = _resolve()
+    R = RigEngine(mdl, cams, n_poses, dev, lib=lib)
     comm = _comm or Comm()
     R.set_params(0, intr0, np.zeros((nC, 6)))
     if _init is None:

@@ -16,12 +16,23 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def emu():
-    """CPU lane emulator of libcamcal.so (test infrastructure, see tests/hostemu)."""
+def _emu_lib():
     if not os.path.exists(EMU_PATH):
         subprocess.run(["make", "-C", ROOT, "hostemu"], check=True)
     from cameracalibration_amd import _lib
     return _lib.load(EMU_PATH)
+
+
+@pytest.fixture()
+def emu(_emu_lib):
+    """CPU lane emulator of libcamcal.so (test infrastructure, see tests/hostemu).  While a test
+    holds this fixture every call of the package runs on it (api._set_test_backend, the package's
+    one test hook); explicit Engine(..., lib=emu) constructions work as before."""
+    import torch
+    from cameracalibration_amd import api
+    api._set_test_backend(_emu_lib, torch.device("cpu"))
+    yield _emu_lib
+    api._set_test_backend(None, None)
 
 
 @pytest.fixture(scope="session")

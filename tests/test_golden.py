@@ -59,7 +59,7 @@ def test_host_logic_on_emulator_reproduces_golden(path, emu):
     z, objs, imgs, crit = load(path)
     size = tuple(int(v) for v in z["image_size"])
     info = {}
-    kw = dict(flags=int(z["flags"]), criteria=crit, _lib_override=emu, _device_override=torch.device("cpu"), _info=info)
+    kw = dict(flags=int(z["flags"]), criteria=crit, _info=info)
     if str(z["model"]) == "pinhole":
         r = cc.calibrateCamera(objs, imgs, size, z["K_guess"].copy(), z["D_guess"].copy(), **kw)
     else:

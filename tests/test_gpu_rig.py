@@ -80,7 +80,7 @@ def test_rig_solve_matches_oracle_gpu(dev):
     objs, imgs = R.as_lists()
     Ks, Ds = R.guess_matrices()
     info = {"init": True}
-    out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _device_override=dev,
+    out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7),
                             _info=info)
     rms, intr, ext, poses, oi = OR.rig_calibrate("fisheye", objs, imgs, R.intr_guess, max_iter=50, eps=1e-7)
     assert np.allclose(info["init"][1], oi["init"][0], atol=1e-8)
@@ -97,7 +97,7 @@ def test_rig_golden_gpu(dev):
     z, cams, Ks, Ds = load_rig_golden()
     info = {}
     out = rig.calibrate_rig(None, None, tuple(z["image_size"]), Ks, Ds, criteria=(3, 40, 1e-7), cams=cams,
-                            n_poses=int(z["n_poses"]), _device_override=dev, _info=info)
+                            n_poses=int(z["n_poses"]), _info=info)
     check_rig_golden(z, out, info)
 
 
@@ -107,7 +107,7 @@ def test_single_camera_rig_is_calibrate_camera_gpu(dev):
     objs, imgs = P.as_lists()
     info, ref_info = {}, {}
     out = rig.calibrate_rig([objs], [imgs], P.image_size, [P.K_guess], [P.D_guess], model="pinhole",
-                            criteria=(3, 100, 1e-6), _device_override=dev, _info=info)
+                            criteria=(3, 100, 1e-6), _info=info)
     ref = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1,
                              criteria=(3, 100, 1e-6), _info=ref_info)
     assert info["iters"] == ref_info["iters"]
@@ -126,7 +126,7 @@ def test_config4_full_size_recovers_truth(dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 30, 1e-7), cams=cams,
-                            n_poses=R.n_poses, _device_override=dev, _info=info)
+                            n_poses=R.n_poses, _info=info)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     n_obs = R.n_obs
@@ -154,6 +154,6 @@ def test_config4_full_size_recovers_truth(dev):
     D2 = [d.copy() for d in out[2]]
     info2 = {}
     out2 = rig.calibrate_rig(None, None, R.image_size, K2, D2, criteria=(3, 30, 1e-7), cams=cams,
-                             n_poses=R.n_poses, _device_override=dev, _info=info2, _init=(ext, poses))
+                             n_poses=R.n_poses, _info=info2, _init=(ext, poses))
     assert info2["iters"] <= 2 and abs(out2[0] - out[0]) < 1e-8
     assert np.allclose(np.stack(out2[1]), np.stack(out[1]), rtol=1e-8)

@@ -61,7 +61,7 @@ def test_shard_ranges_balance_and_cover():
 
 
 def _emu_kw(emu):
-    return dict(_lib_override=emu, _device_override=CPU)
+    return dict()                          # the emu fixture routes the package to the emulator
 
 
 def test_calibrate_camera_signature_and_inplace(emu):
@@ -258,15 +258,14 @@ def test_four_coefficient_guess_is_padded_like_cv2(emu):
     for shape, want in (((4, 1), (5, 1)), ((1, 4), (1, 5)), ((4,), (5, 1))):
         D4 = P.D_guess.ravel()[:4].reshape(shape).copy()
         keep = D4.copy()
-        r = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), D4, flags=1, criteria=CRIT,
-                               _lib_override=emu, _device_override=CPU)
+        r = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), D4, flags=1, criteria=CRIT)
         assert r[2].shape == want and r[2] is not D4 and np.array_equal(D4, keep)
         assert abs(r[2].ravel()[4]) > 1e-3                        # k3 was estimated
     o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess.ravel()[:4].reshape(4, 1), flags=1,
                            criteria=CRIT, solver="dense")
     assert o[2].shape == (5, 1) and abs(r[0] - o[0]) < 1e-9 and np.allclose(r[2].ravel(), o[2].ravel(), rtol=1e-6, atol=1e-9)
     rf = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.ravel()[:4].copy(),
-                            flags=1 | cc.CALIB_FIX_K3, criteria=CRIT, _lib_override=emu, _device_override=CPU)
+                            flags=1 | cc.CALIB_FIX_K3, criteria=CRIT)
     assert rf[2].shape == (5, 1) and rf[2][4, 0] == 0.0
 
 
@@ -283,8 +282,7 @@ def test_degenerate_view_raises_and_names_it(emu):
         i5[:, 0, 0] = i5[0, 0, 0] + o5[:, 0, 0]
         objs[5], imgs[5] = o5, i5
         with pytest.raises(cc.error) as ei:
-            fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT,
-               _lib_override=emu, _device_override=CPU)
+            fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT)
         assert "5" in str(ei.value)
 
 
@@ -318,4 +316,4 @@ def cap_hitting_case(fn_kwargs):
 
 
 def test_cap_hitting_views_match_the_reinitialising_oracle(emu):
-    cap_hitting_case(dict(_lib_override=emu, _device_override=CPU))
+    cap_hitting_case(dict())

@@ -81,8 +81,7 @@ def test_emulated_rig_matches_oracle(emu):
     objs, imgs = R.as_lists()
     Ks, Ds = R.guess_matrices()
     info = {"init": True}
-    out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _lib_override=emu,
-                            _device_override=CPU, _info=info)
+    out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _info=info)
     log = []
     rms, intr, ext, poses, oi = OR.rig_calibrate("fisheye", objs, imgs, R.intr_guess, max_iter=50, eps=1e-7,
                                                  log=log)
@@ -143,10 +142,10 @@ def test_single_camera_rig_is_calibrate_camera(emu):
     objs, imgs = P.as_lists()
     info = {}
     out = rig.calibrate_rig([objs], [imgs], P.image_size, [P.K_guess], [P.D_guess], model="pinhole",
-                            criteria=(3, 100, 1e-6), _lib_override=emu, _device_override=CPU, _info=info)
+                            criteria=(3, 100, 1e-6), _info=info)
     ref_info = {}
     ref = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1,
-                             criteria=(3, 100, 1e-6), _lib_override=emu, _device_override=CPU, _info=ref_info)
+                             criteria=(3, 100, 1e-6), _info=ref_info)
     assert info["iters"] == ref_info["iters"]
     assert abs(out[0] - ref[0]) < 1e-9
     assert np.allclose(out[1][0], ref[1], rtol=1e-8) and np.allclose(out[2][0], ref[2], rtol=1e-6, atol=1e-10)
@@ -163,11 +162,10 @@ def test_single_camera_fisheye_rig_reaches_fisheye_minimum(emu):
     import cameracalibration_amd as cc
     P = synth.config("C2", n_views=40)
     objs, imgs = P.as_lists()
-    out = rig.calibrate_rig([objs], [imgs], P.image_size, [P.K_guess], [P.D_guess], criteria=(3, 100, 1e-12),
-                            _lib_override=emu, _device_override=CPU)
+    out = rig.calibrate_rig([objs], [imgs], P.image_size, [P.K_guess], [P.D_guess], criteria=(3, 100, 1e-12))
     fl = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
     ref = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl,
-                               criteria=(3, 300, 1e-13), _lib_override=emu, _device_override=CPU)
+                               criteria=(3, 300, 1e-13))
     assert abs(out[0] - ref[0]) < 1e-8
     assert np.allclose(out[1][0], ref[1], rtol=1e-6) and np.allclose(out[2][0], ref[2], rtol=1e-3, atol=1e-7)
 
@@ -194,7 +192,7 @@ def test_rig_golden_on_emulator(emu):
     z, cams, Ks, Ds = load_rig_golden()
     info = {}
     out = rig.calibrate_rig(None, None, tuple(z["image_size"]), Ks, Ds, criteria=(3, 40, 1e-7), cams=cams,
-                            n_poses=int(z["n_poses"]), _lib_override=emu, _device_override=CPU, _info=info)
+                            n_poses=int(z["n_poses"]), _info=info)
     check_rig_golden(z, out, info)
 
 
@@ -203,14 +201,14 @@ def test_rig_rejects_bad_input(emu):
     objs, imgs = R.as_lists()
     Ks, Ds = R.guess_matrices()
     with pytest.raises(ValueError):
-        rig.calibrate_rig(objs, imgs[:1], R.image_size, Ks, Ds, _lib_override=emu, _device_override=CPU)
+        rig.calibrate_rig(objs, imgs[:1], R.image_size, Ks, Ds)
     with pytest.raises(ValueError):
-        rig.calibrate_rig(objs, imgs, R.image_size, Ks[:1], Ds, _lib_override=emu, _device_override=CPU)
+        rig.calibrate_rig(objs, imgs, R.image_size, Ks[:1], Ds)
     # camera 1 sharing no pose with camera 0
     o2 = [objs[0], [None] * 6]
     i2 = [imgs[0], [None] * 6]
     with pytest.raises(ValueError):
-        rig.calibrate_rig(o2, i2, R.image_size, Ks, Ds, _lib_override=emu, _device_override=CPU)
+        rig.calibrate_rig(o2, i2, R.image_size, Ks, Ds)
 
 
 # --- two ranks over gloo -----------------------------------------------------
@@ -232,12 +230,13 @@ def _worker(rank, world, port, out_dir):
     from cameracalibration_amd.distributed import shard_rig_lists
     from cameracalibration_amd.solver import Comm
     emu = _lib.load(EMU)
+    from cameracalibration_amd import api
+    api._set_test_backend(emu, torch.device("cpu"))      # the workers run on the CPU lane emulator
     R = small_rig(24, 3, seed=5)
     objs, imgs = R.as_lists()
     o, i, (lo, hi) = shard_rig_lists(objs, imgs, rank, world)
     Ks, Ds = R.guess_matrices()
-    r = rig.calibrate_rig(o, i, R.image_size, Ks, Ds, criteria=(3, 40, 1e-9), _lib_override=emu,
-                          _device_override=CPU, _comm=Comm())
+    r = rig.calibrate_rig(o, i, R.image_size, Ks, Ds, criteria=(3, 40, 1e-9), _comm=Comm())
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), rms=r[0], K=np.stack(r[1]), D=np.stack(r[2]),
              T=np.stack([np.vstack(t) for t in r[3]]), rv=np.hstack(r[4]).T, tv=np.hstack(r[5]).T, lo=lo, hi=hi)
     dist.destroy_process_group()
@@ -249,8 +248,7 @@ def test_two_rank_rig_equals_single_rank(emu, tmp_path):
     R = small_rig(24, 3, seed=5)
     objs, imgs = R.as_lists()
     Ks, Ds = R.guess_matrices()
-    ref = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 40, 1e-9), _lib_override=emu,
-                            _device_override=CPU)
+    ref = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 40, 1e-9))
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     assert parts[0]["lo"] == 0 and parts[0]["hi"] == parts[1]["lo"] and parts[1]["hi"] == 24
     for p in parts:
@@ -272,8 +270,7 @@ def test_library_sequenced_rig_loop_equals_the_python_loop(emu):
     Ks, Ds = R.guess_matrices()
     res = []
     for info in ({}, {"log": True}):
-        out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _lib_override=emu,
-                                _device_override=CPU, _info=info)
+        out = rig.calibrate_rig(objs, imgs, R.image_size, Ks, Ds, criteria=(3, 50, 1e-7), _info=info)
         res.append((out, info))
     (a, ia), (b, ib) = res
     assert ia["log"] is None and len(ib["log"]) == ib["iters"] == ia["iters"]
