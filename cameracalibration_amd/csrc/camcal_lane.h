@@ -662,10 +662,11 @@ CC_HD int pose_init_walk(const float* base, int n, int k0, int step, const doubl
       dmax = fmax(dmax, fabs(b[i]));
       hmax = fmax(hmax, fabs(h[i]));
     }
-    // Gauss-Newton converges quadratically here: a step below 1e-8 leaves an error near
-    // 1e-16, so the pass that would only confirm it is not run (cv2's LM refinement of
-    // the homography stops at FLT_EPSILON)
-    if (dmax <= 1e-8 * hmax) break;
+    // Near its minimum this Gauss-Newton contracts by the relative transfer residual per step
+    // (1e-3 or better on calibration boards), so the step after one of 1e-5 would move the
+    // homography by about 1e-8: below FLT_EPSILON, where cv2's own LM refinement of the
+    // homography stops.  The pass that would only confirm it is not run.
+    if (dmax <= 1e-5 * hmax) break;
   }
   // columns of the homography in centred board millimetres
   double h1[3] = {h[0] * iX, h[3] * iX, h[6] * iX};
