@@ -201,45 +201,66 @@ CC_HD void lane_cross_block(const LaneTile& tv, const double* intr, const double
 // stop when ||d|| / ||x + d|| <= tol, when cond(J) > 1e6 (fisheye: the view keeps
 // the pose it has, as in cv2) or after max_iter steps.  Returns the number of steps taken.
 
-// Eigenvalues of a symmetric 6x6 (packed upper, destroyed): cyclic Jacobi, 6 sweeps.
-// Only the extreme ones are wanted, to ~1e-16 of the largest.
-CC_HD void sym6_eig_range(double A[21], double& lo, double& hi) {
+// Extreme eigenvalues of the symmetric 6x6 matrix U^T U (U upper, packed): cyclic Jacobi,
+// 6 sweeps, to ~1e-16 of the largest.  Written with run-time loops on purpose: the matrix
+// then lives in scratch memory and is touched only by the rare view that gets here; fully
+// unrolled it sat in 42 registers and made the refinement kernel spill on its hot path.
+CC_HD void gram6_eig_range(const double U[21], double& lo, double& hi) {
+  double A[6][6];
+  CC_UNROLL
+  for (int i = 0; i < 6; ++i)
+    CC_UNROLL
+    for (int j = i; j < 6; ++j) {
+      double sm = 0.0;
+      CC_UNROLL
+      for (int k = 0; k <= i; ++k) sm = fma(U[tri(6, k, i)], U[tri(6, k, j)], sm);
+      A[i][j] = sm;
+      A[j][i] = sm;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
   for (int sweep = 0; sweep < 6; ++sweep) {
-    CC_UNROLL
-    for (int p = 0; p < 5; ++p)
-      CC_UNROLL
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int p = 0; p < 5; ++p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
       for (int q = p + 1; q < 6; ++q) {
-        const double apq = A[tri(6, p, q)];
-        const double app = A[tri(6, p, p)], aqq = A[tri(6, q, q)];
-        // a rotation by (near) zero where the entry is already negligible
+        const double apq = A[p][q], app = A[p][p], aqq = A[q][q];
+        // a rotation by zero where the entry is already negligible
         const bool live = fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * (fabs(app) + fabs(aqq));
         const double th = live ? (aqq - app) / (2.0 * apq) : 0.0;
         double t = 1.0 / (fabs(th) + sqrt(th * th + 1.0));
         t = th < 0.0 ? -t : t;
         t = live ? t : 0.0;
         const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-        A[tri(6, p, p)] = app - t * apq;
-        A[tri(6, q, q)] = aqq + t * apq;
-        A[tri(6, p, q)] = live ? 0.0 : apq;
-        CC_UNROLL
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
         for (int k = 0; k < 6; ++k) {
-          if (k == p || k == q) continue;
-          const int ikp = k < p ? tri(6, k, p) : tri(6, p, k), ikq = k < q ? tri(6, k, q) : tri(6, q, k);
-          const double akp = A[ikp], akq = A[ikq];
-          A[ikp] = c * akp - sn * akq;
-          A[ikq] = sn * akp + c * akq;
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (int k = 0; k < 6; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
         }
       }
+    }
   }
-  lo = A[tri(6, 0, 0)];
+  lo = A[0][0];
   hi = lo;
-  CC_UNROLL
   for (int i = 1; i < 6; ++i) {
-    lo = fmin(lo, A[tri(6, i, i)]);
-    hi = fmax(hi, A[tri(6, i, i)]);
+    lo = fmin(lo, A[i][i]);
+    hi = fmax(hi, A[i][i]);
   }
 }
 
@@ -275,18 +296,8 @@ CC_HD bool pose_cond_tripped(const double U[21], const double inv_diag[6], doubl
   }
   if (dmax * dinv > thresh2) return true;
   if (tr * tinv <= thresh2) return false;
-  double A[21];                                    // J^T J back from its factor
-  CC_UNROLL
-  for (int i = 0; i < 6; ++i)
-    CC_UNROLL
-    for (int j = i; j < 6; ++j) {
-      double sm = 0.0;
-      CC_UNROLL
-      for (int k = 0; k <= i; ++k) sm = fma(U[tri(6, k, i)], U[tri(6, k, j)], sm);
-      A[tri(6, i, j)] = sm;
-    }
   double lo, hi;
-  sym6_eig_range(A, lo, hi);
+  gram6_eig_range(U, lo, hi);
   return !(lo > 0.0) || hi > thresh2 * lo;
 }
 
