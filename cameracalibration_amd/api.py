@@ -111,23 +111,33 @@ def _gather_views(object_points, image_points, min_points=4):
     if nv == 0 or nv != ni:
         raise error("objectPoints and imagePoints must be non-empty and of equal length "
                     "(nimages > 0 && nimages == (int)imagePoints.total())")
-    if all(type(o) is np.ndarray for o in object_points) and all(type(i) is np.ndarray for i in image_points):
-        # the usual call: lists of ndarrays -- sizes and one concatenation, no per-view conversions
-        so = np.fromiter((o.size for o in object_points), dtype=np.int64, count=nv)
-        si = np.fromiter((i.size for i in image_points), dtype=np.int64, count=nv)
+    if set(map(type, object_points)) == {np.ndarray} and set(map(type, image_points)) == {np.ndarray}:
+        # the usual call: lists of ndarrays -- one concatenation each, no per-view conversions
+        try:                                   # equal trailing shapes ((n,1,3) / (n,3)): one C call each
+            cat_o = np.concatenate(object_points, axis=0)
+            cat_i = np.concatenate(image_points, axis=0)
+            # rows per view from the leading dimensions when a row is one point (len() is much
+            # cheaper than .size over a list), else from the sizes
+            if cat_o.ndim > 1 and cat_i.ndim > 1 and cat_o[0].size == 3 and cat_i[0].size == 2:
+                counts = np.array(list(map(len, object_points)), dtype=np.int64)
+                ci = np.array(list(map(len, image_points)), dtype=np.int64)
+                so, si = counts * 3, ci * 2
+            else:
+                so = si = None
+        except ValueError:                     # mixed layouts: flatten per view
+            cat_o = np.concatenate([o.ravel() for o in object_points])
+            cat_i = np.concatenate([i.ravel() for i in image_points])
+            so = si = None
+        if so is None:
+            so = np.fromiter((o.size for o in object_points), dtype=np.int64, count=nv)
+            si = np.fromiter((i.size for i in image_points), dtype=np.int64, count=nv)
         if np.any(so % 3) or np.any(si % 2):
             raise error("objectPoints must be Nx3 / imagePoints Nx2")
         counts = so // 3
         if np.any(counts != si // 2):
             raise error("number of object and image points must be equal in every view")
-        if np.any(counts < min_points):
+        if counts.min() < min_points:
             raise error("every view needs at least %d points" % min_points)
-        try:                                   # equal trailing shapes ((n,1,3) / (n,3)): one C call each
-            cat_o = np.concatenate(object_points, axis=0)
-            cat_i = np.concatenate(image_points, axis=0)
-        except ValueError:                     # mixed layouts: flatten per view
-            cat_o = np.concatenate([o.ravel() for o in object_points])
-            cat_i = np.concatenate([i.ravel() for i in image_points])
         objs = [cat_o.astype(np.float32, copy=False).reshape(-1, 3)]
         imgs = [cat_i.astype(np.float32, copy=False).reshape(-1, 2)]
     else:
@@ -148,9 +158,9 @@ def _gather_views(object_points, image_points, min_points=4):
             counts.append(o.shape[0])
     view_ptr = np.zeros(nv + 1, dtype=np.int64)
     view_ptr[1:] = np.cumsum(counts)
-    obj = np.concatenate(objs, axis=0)
-    img = np.concatenate(imgs, axis=0)
-    if np.any(obj[:, 2] != 0.0):
+    obj = objs[0] if len(objs) == 1 else np.concatenate(objs, axis=0)
+    img = imgs[0] if len(imgs) == 1 else np.concatenate(imgs, axis=0)
+    if obj[:, 2].any():
         raise error("only planar calibration targets with Z = 0 are supported "
                     "(the reference's chessboard / ChArUco boards)")
     return view_ptr, obj, img
