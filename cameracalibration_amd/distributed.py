@@ -49,3 +49,25 @@ def shard_rig_lists(object_points, image_points, rank, world):
                 n[p] += len(o)
     lo, hi = shard_ranges(n, world)[rank]
     return ([list(cam[lo:hi]) for cam in object_points], [list(cam[lo:hi]) for cam in image_points], (lo, hi))
+
+
+def shard_rig_cams(cams, n_poses, rank, world):
+    """The packed form of :func:`shard_rig_lists`: ``cams`` = per camera dict(pose_idx (sorted, numpy),
+    view_ptr, obj, img) as rig.calibrate_rig(cams=...) takes them.  Returns (cams of this rank with
+    pose indices rebased to its range, poses in the range, (lo, hi))."""
+    n = np.zeros(int(n_poses), dtype=np.int64)
+    for c in cams:
+        pi = np.asarray(c["pose_idx"], dtype=np.int64)
+        vp = np.asarray(c["view_ptr"].cpu() if hasattr(c["view_ptr"], "cpu") else c["view_ptr"], dtype=np.int64)
+        if pi.size > 1 and np.any(np.diff(pi) <= 0):
+            raise ValueError("pose_idx must be strictly increasing per camera")
+        n[pi] += np.diff(vp)
+    lo, hi = shard_ranges(n, world)[rank]
+    out = []
+    for c in cams:
+        pi = np.asarray(c["pose_idx"], dtype=np.int64)
+        vp = c["view_ptr"]
+        a, b = int(np.searchsorted(pi, lo, side="left")), int(np.searchsorted(pi, hi, side="left"))
+        p0, p1 = int(vp[a]), int(vp[b])
+        out.append(dict(pose_idx=pi[a:b] - lo, view_ptr=vp[a:b + 1] - vp[a], obj=c["obj"][p0:p1], img=c["img"][p0:p1]))
+    return out, hi - lo, (lo, hi)

@@ -278,3 +278,27 @@ def test_library_sequenced_rig_loop_equals_the_python_loop(emu):
     for x, y in zip(a[1] + a[2], b[1] + b[2]):
         assert np.array_equal(x, y)
     assert np.array_equal(np.hstack(a[4]), np.hstack(b[4]))
+
+
+def test_packed_rig_shards_partition_the_views():
+    """distributed.shard_rig_cams (the packed form bench.py's sharded C4 solve uses): the shards of
+    1, 2 and 3 ranks cover every view exactly once, in order, with rebased pose indices and CSR offsets."""
+    from cameracalibration_amd.distributed import shard_rig_cams
+    R = synth.config("C4", n_views=200)
+    cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c]) for c in range(R.n_cams)]
+    for world in (1, 2, 3):
+        parts = [shard_rig_cams(cams, R.n_poses, r, world) for r in range(world)]
+        assert parts[0][2][0] == 0 and parts[-1][2][1] == R.n_poses
+        assert all(parts[r][2][1] == parts[r + 1][2][0] for r in range(world - 1))
+        for c in range(R.n_cams):
+            pi = np.concatenate([p[0][c]["pose_idx"] + p[2][0] for p in parts])
+            assert np.array_equal(pi, R.pose_idx[c])
+            for key in ("obj", "img"):
+                got = np.concatenate([np.asarray(p[0][c][key]) for p in parts])
+                assert np.array_equal(got, np.asarray(getattr(R, key)[c]))
+            n = np.concatenate([np.diff(np.asarray(p[0][c]["view_ptr"])) for p in parts])
+            assert np.array_equal(n, np.diff(np.asarray(R.view_ptr[c])))
+            for p in parts:
+                assert int(p[0][c]["view_ptr"][0]) == 0 and int(p[0][c]["view_ptr"][-1]) == len(p[0][c]["obj"])
+                assert p[0][c]["pose_idx"].size == 0 or (0 <= p[0][c]["pose_idx"].min()
+                                                          and p[0][c]["pose_idx"].max() < p[1])
