@@ -280,7 +280,7 @@ __global__ __launch_bounds__(TPB) void k_rig_pose_schur(int n_cams, int64_t P, c
 typedef double rig_f64x4 __attribute__((ext_vector_type(4)));
 constexpr int RIG_GRAM_TILES = 10;                 // (ti <= tj) of a 4 x 4 tile grid
 constexpr int RIG_GRAM_VALS = RIG_GRAM_TILES * 4 * 64;
-constexpr int RIG_GRAM_MAX_WAVES = 128;
+constexpr int RIG_GRAM_MAX_WAVES = 204;                 // x 5 tile pairs = 1020 wavefronts, one per SIMD (128: C4 0.25 ms slower)
 
 // One wavefront = (chunk group, tile pair): the 10 tiles are 5 pairs, so five times as many
 // wavefronts share the MFMA work of a chunk (a 16x16x4 f64 MFMA occupies a SIMD for 64
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(RIG_GF_WAVES * 64) void k_rig_gram_finalize(int n, 
   __shared__ double sh[RIG_GF_WAVES][64];
   const int row = blockIdx.x;                       // (tile index, register): 64 values, one per lane
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  // 8 partials per wavefront at RIG_GRAM_MAX_WAVES groups, all loads in flight; fixed order
+  // <= 13 partials per wavefront at RIG_GRAM_MAX_WAVES groups, eight loads in flight; fixed order
   double s = 0.0;
 #pragma unroll 8
   for (int w = q; w < n_waves; w += RIG_GF_WAVES) s += part[(int64_t)w * RIG_GRAM_VALS + row * 64 + lane];
