@@ -415,3 +415,48 @@ def case_condition_guard():
 
 
 ALL.append(case_condition_guard)
+
+
+def case_extreme_raggedness():
+    """Views of 4 corners (cv2's minimum) beside views of a 60 x 40 = 2400-corner board in one set: the
+    tiles then differ by a factor 600 in length, a group of lanes walks a view in 38 / 150 trips or has
+    60 of 64 lanes idle.  Whole solve against the oracle, every lane mapping."""
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    big = synth.make_problem("fisheye", 40, synth.board_points(60, 40, 6.0), (2960, 1664), synth.FISHEYE_TRUE_K,
+                             synth.FISHEYE_TRUE_D, synth.FISHEYE_GUESS_K, synth.FISHEYE_GUESS_D, seed=21, noise=0.2,
+                             ragged=(4, 2400))
+    n = np.diff(big.view_ptr)
+    n[::5] = 4                                          # every fifth view keeps its first four kept corners
+    obj, img = big.obj.numpy(), big.img.numpy()
+    objs, imgs = [], []
+    for v in range(40):
+        a = big.view_ptr[v]
+        o, i = obj[a:a + n[v]], img[a:a + n[v]]
+        if n[v] == 4:                                   # four corners in general position (not collinear)
+            full_o, full_i = obj[a:big.view_ptr[v + 1]], img[a:big.view_ptr[v + 1]]
+            sm, df = full_o[:, 0] + full_o[:, 1], full_o[:, 0] - full_o[:, 1]
+            pick = np.array([sm.argmin(), sm.argmax(), df.argmin(), df.argmax()])   # the extreme corners of the board
+            assert len(set(pick.tolist())) == 4
+            o, i = full_o[pick], full_i[pick]
+        objs.append(o.reshape(-1, 1, 3))
+        imgs.append(i.reshape(-1, 1, 2))
+    assert min(len(o) for o in objs) == 4 and max(len(o) for o in objs) > 1500
+    crit = (3, 200, 1e-8)
+    ref = O.fisheye_calibrate(objs, imgs, big.image_size, big.K_guess, big.D_guess, flags=FE, criteria=crit,
+                              solver="schur")
+    for lpv in (1, 16, 64):
+        Engine.LANES_PER_VIEW = lpv
+        try:
+            info = {}
+            r = cc.fisheye.calibrate(objs, imgs, big.image_size, big.K_guess.copy(), big.D_guess.copy(), flags=FE,
+                                     criteria=crit, _info=info)
+        finally:
+            Engine.LANES_PER_VIEW = 0
+        assert info["iters"] == ref[5]["iters"] and abs(r[0] - ref[0]) < 1e-9
+        assert np.allclose(r[1], ref[1], rtol=1e-8) and np.allclose(r[2].ravel(), ref[2].ravel(), rtol=1e-6, atol=1e-10)
+        assert np.allclose(np.hstack(r[4]).T, ref[4], rtol=1e-6, atol=1e-5)
+
+
+ALL.append(case_extreme_raggedness)
