@@ -31,6 +31,8 @@ namespace {
 constexpr int TPB = 256;                 // 4 wavefronts per workgroup
 constexpr int WPB = TPB / LANES;
 constexpr int MAX_WAVES = 4096;          // persistent waves of a reducing kernel (16 per CU)
+constexpr int PARTIAL_STRIDE = 16384;    // row stride of the partial records in scratch: persistent kernels write <= MAX_WAVES
+                                         // of them, grouped launches one per wavefront (16 lanes per view: tiles x 16)
 constexpr int MAX_NV = 96;               // widest reduced record (rig assemble, pinhole: 54 + 21 + 6 = 81)
 
 #define DISPATCH_MODEL_PLANAR(model, planar, L)                       \
@@ -180,7 +182,7 @@ __device__ __forceinline__ void wave_scatter_store(double* v, int lane, double* 
 
 template <int NV>
 __device__ __forceinline__ void wave_reduce_store(double* v, double* scratch, int wave_id) {
-  wave_scatter_store<NV>(v, threadIdx.x & 63, scratch + wave_id, MAX_WAVES);
+  wave_scatter_store<NV>(v, threadIdx.x & 63, scratch + wave_id, PARTIAL_STRIDE);
 }
 
 // this thread's share of a row of partials: elements tid, tid + TPB, ... in four independent
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(TPB) void k_finalize(const double* __restrict__ scr
                                                   double* __restrict__ out) {
   __shared__ double sh[TPB];
   const int i = blockIdx.x;
-  const double s = strided_partial_sum(scratch + (size_t)i * MAX_WAVES, n_waves);
+  const double s = strided_partial_sum(scratch + (size_t)i * PARTIAL_STRIDE, n_waves);
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int st = TPB / 2; st >= 1; st >>= 1) {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(TPB) void k_intr_normal(camcal_tiles t, const doubl
     wave_reduce_store<NR>(acc.v, scratch, wave);
   } else {
     const double s = wave_sum(acc.v[COST]);
-    if (lane == 0) scratch[(size_t)COST * MAX_WAVES + wave] = s;
+    if (lane == 0) scratch[(size_t)COST * PARTIAL_STRIDE + wave] = s;
   }
 }
 
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(TPB) void k_intr_normal_grp(camcal_tiles t, const d
     wave_reduce_store<NR>(acc.v, scratch, wave);
   } else {
     const double s = wave_sum(acc.v[COST]);
-    if (lane == 0) scratch[(size_t)COST * MAX_WAVES + wave] = s;
+    if (lane == 0) scratch[(size_t)COST * PARTIAL_STRIDE + wave] = s;
   }
 }
 
@@ -1171,10 +1173,10 @@ inline int grid_persistent(const camcal_tiles* t) {
 // small planar sets.  The partial records of a grouped launch are one per wavefront
 // (n_tiles * G of them) and must fit the scratch every caller holds (camcal_scratch_len).
 constexpr int GROUP64_MAX_TILES = 32;      // <= 2048 views: one wavefront per view
-constexpr int GROUP16_MAX_TILES = 256;     // <= 16384 views: four views per wavefront (measured ahead of one lane per view up to
-                                           // 32768; 256 tiles x 16 = MAX_WAVES partial records is what the scratch layouts hold)
-static_assert(GROUP64_MAX_TILES * 64 <= MAX_WAVES && GROUP16_MAX_TILES * 16 <= MAX_WAVES,
-              "grouped launches write one partial record per wavefront into MAX_WAVES-strided scratch");
+constexpr int GROUP16_MAX_TILES = 448;     // <= 28672 views: four views per wavefront (tools/gpu_lanes.py: ahead of one lane per
+                                           // view up to ~30 000 views, full boards and ragged ones alike; 2.4 vs 3.9 ms at 12 000)
+static_assert(GROUP64_MAX_TILES * 64 <= PARTIAL_STRIDE && GROUP16_MAX_TILES * 16 <= PARTIAL_STRIDE,
+              "grouped launches write one partial record per wavefront into PARTIAL_STRIDE-strided scratch");
 inline int group_lanes(const camcal_tiles* t) {
   const int want = t->lanes_per_view;      // 0: by size
   if (!t->planar || want == 1) return 1;
@@ -1233,8 +1235,8 @@ int camcal_schur_len(int model) {
 }
 int64_t camcal_scratch_len(int model, int n_tiles) {
   (void)model;
-  // persistent / grouped launches: <= MAX_WAVES partial records of <= STATIC_ROWS values; one lane per view: one per tile
-  const int64_t a = (int64_t)STATIC_ROWS * MAX_WAVES, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
+  // persistent / grouped launches: <= PARTIAL_STRIDE partial records of <= STATIC_ROWS values; one lane per view: one per tile
+  const int64_t a = (int64_t)STATIC_ROWS * PARTIAL_STRIDE, b = (int64_t)2 * MAX_NV * (n_tiles > 0 ? n_tiles : 0);
   return (a > b ? a : b) + 2 * MAX_NV;   // + the reduced values ahead of their expansion
 }
 
@@ -1341,12 +1343,12 @@ int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
   int gp = grid_persistent(tiles);
   const dim3 b(TPB);
   hipStream_t s = (hipStream_t)stream;
-  double* red = scratch + (size_t)MAX_NV * MAX_WAVES;      // reduced values ahead of their expansion
+  double* red = scratch + (size_t)MAX_NV * PARTIAL_STRIDE; // reduced values ahead of their expansion
   const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
   const int ci = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::COST : IntrAcc<FISHEYE>::COST;
   const int G = group_lanes(tiles);
   if (G > 1) {
-    gp = grid_groups(tiles, G);                             // one partial per wavefront, <= MAX_WAVES of them
+    gp = grid_groups(tiles, G);                             // one partial per wavefront, <= PARTIAL_STRIDE of them
     const dim3 gg(gp);
     const int mode = (with_normal && V) ? 2 : with_normal ? 1 : 0;
 #define LAUNCHG(M, MODE, GG) hipLaunchKernelGGL((k_intr_normal_grp<M, MODE, GG>), gg, b, 0, s, *tiles, intr, pose, view_cost, V, g, scratch)
@@ -1369,7 +1371,7 @@ int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr,
   }
   HIP_TRY(hipGetLastError());
   if (with_normal) hipLaunchKernelGGL(k_finalize, dim3(nr), dim3(TPB), 0, s, scratch, gp * WPB, red);
-  else hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)ci * MAX_WAVES, gp * WPB, red + ci);
+  else hipLaunchKernelGGL(k_finalize, dim3(1), dim3(TPB), 0, s, scratch + (size_t)ci * PARTIAL_STRIDE, gp * WPB, red + ci);
   HIP_TRY(hipGetLastError());
   if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, 0, with_normal ? 0 : 1);
   else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, 0, with_normal ? 0 : 1);

@@ -61,7 +61,7 @@ typedef struct camcal_tiles {
   int32_t        lanes_per_view; /* how many lanes share one view in the per-view
                                 kernels: 0 = chosen by the size of the set (one lane per
                                 view for large sets -- the throughput mapping --, 16 or 64
-                                lanes per view for small planar sets of <= 16384 / <= 2048
+                                lanes per view for small planar sets of <= 28672 / <= 2048
                                 views, so that a production-sized call (20 ... 500 views,
                                 intrinsicCalib.py:102-105) spreads over the whole device
                                 instead of a handful of wavefronts); 1, 16 or 64 force a

@@ -219,9 +219,9 @@ def test_library_sequenced_loops_equal_the_python_loops_on_gpu(dev):
         assert np.array_equal(np.hstack(a[3]), np.hstack(b[3]))
 
 
-@pytest.mark.parametrize("nv", [1, 63, 65, 2048, 2049, 16384, 16385])
+@pytest.mark.parametrize("nv", [1, 63, 65, 2048, 2049, 28672, 28673])
 def test_automatic_mapping_at_its_size_boundaries(dev, nv):
-    """The mapping chosen by size (64 lanes per view up to 32 tiles, 16 up to 256, one above)
+    """The mapping chosen by size (64 lanes per view up to 32 tiles, 16 up to 448, one above)
     against one lane per view, on ragged sets either side of every boundary: the single-pass
     record, the stored blocks and a pose re-estimation."""
     P = synth.config("C3", n_views=nv)
