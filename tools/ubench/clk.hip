@@ -1,6 +1,7 @@
 // Shader clock under light load (development tool): a single wavefront runs a dependent
 // FMA chain and reports shader cycles (clock64) against the constant 100 MHz counter
 // (wall_clock64), alone and right after a device-filling kernel.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/clk.hip -o tools/ubench/clk
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

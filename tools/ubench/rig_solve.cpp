@@ -1,5 +1,7 @@
 // Timing harness for camcal_rig_solve (development tool): a fake 4-camera fisheye rig
 // whose record holds a diagonally dominant reduced system; times the reduced solve alone.
+//   hipcc -O2 -std=c++17 tools/ubench/rig_solve.cpp -Lcameracalibration_amd/csrc -lcamcal -ldl \
+//         -Wl,-rpath,'$ORIGIN/../../cameracalibration_amd/csrc' -o tools/ubench/rig_solve
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
