@@ -66,3 +66,39 @@ def test_static_scratch_entry_point_rejects_sizes_beyond_its_limit():
     rc = lib.camcal_normal_eq_fused_static(7, C.byref(E.tiles), E.intr[0].data_ptr(), E.pose[0].data_ptr(), 0.0,
                                            E.glob[0].data_ptr(), E.schur.data_ptr(), E._stream())
     assert rc == -2
+
+
+def test_static_scratch_entry_point_replays_from_a_hip_graph():
+    """What the entry point is for: a caller under stream capture cannot allocate.  The evaluation is
+    captured once into a HIP graph and replayed after the intrinsics and the poses changed in place;
+    every replay equals the direct call bit for bit."""
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    P = synth.config("C2", n_views=3000)
+    E = Engine(1, P.view_ptr, P.obj, P.img, dev)
+    E.set_intr(0, P.intr_guess())
+    E.set_poses(0, P.poses_true.numpy())
+
+    def static_call(stream):
+        rc = lib.camcal_normal_eq_fused_static(E.model, C.byref(E.tiles), E.intr[0].data_ptr(), E.pose[0].data_ptr(), 0.0,
+                                               E.glob[0].data_ptr(), E.schur.data_ptr(), C.c_void_p(stream.cuda_stream))
+        assert rc == 0, rc
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        static_call(side)                       # first call outside the capture: the library looks its array up once
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        static_call(torch.cuda.current_stream(dev))
+    for k in range(3):
+        E.intr[0][:4] *= 1.0 + 1e-3 * (k + 1)   # parameters change in place between replays
+        E.pose[0][3] += 0.5
+        E.rec.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        got = E.rec.cpu().numpy().copy()
+        E.rec.fill_(float("nan"))
+        E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
+        want = E.rec.cpu().numpy().copy()
+        assert np.isfinite(got).all() and np.array_equal(got, want)
