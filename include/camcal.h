@@ -82,7 +82,8 @@ int camcal_glob_len(int model);
 int camcal_schur_len(int model);
 
 /* Doubles of scratch the reducing entry points need (partial sums of the
- * launched wavefronts) for a problem of n_tiles tiles. */
+ * launched wavefronts) for a problem of n_tiles tiles: at least 109 x 16384 + 192
+ * (14.3 MB), more above 9300 tiles. */
 int64_t camcal_scratch_len(int model, int n_tiles);
 
 /* Host-side layout of n_views views with the given corner counts (HOST pointers, no
@@ -319,7 +320,9 @@ typedef struct camcal_rig {
 } camcal_rig;
 
 int64_t camcal_rig_rec_len(int model, int n_cams);
-/* n_tiles_host: HOST array [n_cams] of the cameras' tile counts */
+/* n_tiles_host: HOST array [n_cams] of the cameras' tile counts.  The length covers the work
+ * area the stages share and, behind it, 27 doubles per board pose that camcal_rig_eliminate
+ * leaves for camcal_rig_backsub (the pose factors). */
 int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_host, int64_t P);
 
 /* Blocks of the whole rig at parameter buffer b: per camera the single-pass evaluation of
