@@ -199,6 +199,20 @@ def solve_times(dev, with_cpu=True):
         out["C3_fisheye_100k_ragged_views"] = big_solve("C3", 100_000, dev, lib)
         torch.cuda.empty_cache()
         out["C5_fisheye_1M_views"] = big_solve("C5", 1_000_000, dev, lib)
+        if with_cpu:
+            # the CPU restatement beside every config -- on a bounded sample where the full
+            # set would take minutes (the Schur form is linear in the views; cv2's dense form is cubic)
+            from oracle import cvcalib as O
+            for key, name, nv in (("C3_fisheye_100k_ragged_views", "C3", 2000), ("C5_fisheye_1M_views", "C5", 1000)):
+                Ps = synth.config(name, n_views=nv)
+                os_, is_ = Ps.as_lists()
+                t0 = time.perf_counter()
+                r = O.fisheye_calibrate(os_, is_, Ps.image_size, Ps.K_guess, Ps.D_guess, flags=fe, criteria=crit, solver="schur")
+                dt = (time.perf_counter() - t0) * 1e3
+                out[key]["cpu_oracle_sample"] = {"views": nv, "ms": dt, "iterations": int(r[5]["iters"]),
+                                                 "ms_per_1000_views": dt * 1000.0 / nv,
+                                                 "what": "oracle/cvcalib.py Schur-eliminated Gauss-Newton, numpy, 1 thread, on a "
+                                                         "%d-view sample of the same generator (linear in the views)" % nv}
     except Exception as exc:      # reported, never required
         out["error"] = str(exc)
     return out
