@@ -30,6 +30,7 @@ sys.path.insert(0, HERE)
 
 from cameracalibration_amd import _lib, synth  # noqa: E402
 from cameracalibration_amd.engine import Engine  # noqa: E402
+from cameracalibration_amd.solver import _all_reduce  # noqa: E402  (device tensors on a gloo group go through the host)
 
 # Algorithmic work model (BASELINE.md section 3 / SURVEY.md 8d; re-counted in DESIGN.md)
 FLOP_PER_OBS = {"fisheye": 605.0, "pinhole": 732.0}
@@ -239,7 +240,7 @@ def sharded_solves(dev, lib, rank, world, views_total):
             torch.cuda.synchronize()
             t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=dev)
             if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                _all_reduce(t, None, dist.ReduceOp.MAX)
             ms.append(float(t.item()))
         return ms, res
 
@@ -255,7 +256,9 @@ def sharded_solves(dev, lib, rank, world, views_total):
             E.pose_refine(0, 0, 20, 1e-10)
             cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), (3, 1000, 1e-6), comm=comm)
             return cost, it, E.get_intr(0)
+        progress("sharded C5: %d views on this rank" % (hi - lo))
         ms, (cost, it, intr) = wall(c5)
+        progress("sharded C5: %.2f ms" % ms[1])
         n_total = comm.total(P.n_obs, dev)
         out["C5_fisheye_sharded"] = {"ms": ms[1], "first_run_ms": ms[0], "views_total": views_total, "views_on_rank0": hi - lo,
                                      "iterations": it, "rms_px": float(np.sqrt(cost / n_total)),
@@ -275,7 +278,9 @@ def sharded_solves(dev, lib, rank, world, views_total):
             r = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 100, 1e-7), cams=mine, n_poses=n_mine,
                                   _comm=rcomm, _info=info)
             return r[0], info["iters"]
+        progress("sharded C4: %d poses on this rank" % n_mine)
         ms, (rms, it) = wall(c4)
+        progress("sharded C4: %.2f ms" % ms[1])
         out["C4_rig_sharded"] = {"ms": ms[1], "first_run_ms": ms[0], "poses_total": R.n_poses, "poses_on_rank0": n_mine,
                                  "iterations": it, "rms_px": float(rms), "communicator": rcomm.kind,
                                  "note": "board poses split over the ranks, [C|d] and the records summed through the "
@@ -283,6 +288,15 @@ def sharded_solves(dev, lib, rank, world, views_total):
     except Exception as exc:      # reported, never required
         out["error"] = "%s: %s" % (type(exc).__name__, exc)
     return out
+
+
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr per stage (rank, seconds since start): a run that takes minutes shows where it is."""
+    sys.stderr.write("[bench rank %s +%.1fs] %s\n" % (os.environ.get("RANK", "0"), time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
 
 
 def timed_steps(step, steps, world, dev):
@@ -306,7 +320,7 @@ def timed_steps(step, steps, world, dev):
     el = time.perf_counter() - t0
     tmax = torch.tensor([el], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        _all_reduce(tmax, None, dist.ReduceOp.MAX)
     return float(tmax.item()), region_ms
 
 
@@ -416,6 +430,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solves", action="store_true", help="skip the whole-solve wall-clock extras")
     args = ap.parse_args()
+    if os.environ.get("CAMCAL_BENCH_WATCHDOG"):      # seconds: dump every thread's stack and exit if still running
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CAMCAL_BENCH_WATCHDOG"]), exit=True)
 
     # ONE JSON line on stdout: everything else a library may print there (RCCL's version banner at
     # communicator creation, ...) goes to stderr; the line itself is written to the saved descriptor
@@ -428,13 +445,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CAMCAL_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+    # (the ranks share devices; the records travel through torch.distributed over gloo, not RCCL)
+    backend = os.environ.get("CAMCAL_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
     multi = world > 1 or args.force_comm
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = _lib.load()
     from cameracalibration_amd import solver
@@ -452,15 +475,19 @@ def main():
         else:                          # BASELINE config 5 as written: --views in total, sharded by observation count
             lo, hi = shard_ranges(np.full(args.views, 88, dtype=np.int64), world)[rank]
             nv_rank = hi - lo
+        progress("%s scaling: building %d views" % (mode, nv_rank))
         E, n_obs, n_views = make_engine(lib, nv_rank, dev, seed=5 + rank)
         handle = comm.handle(E)
+        progress("communicator: %s" % comm.kind)
         step = make_step(E, lib, handle)
         for _ in range(prewarm + args.warmup):
             step()
+        progress("warm-up done, timing %d steps" % args.steps)
         el, region_ms = timed_steps(step, args.steps, world, dev)
+        progress("timed: %.3f ms/step" % (el / args.steps * 1e3))
         tot = torch.tensor([float(n_obs)], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.all_reduce(tot)
+            _all_reduce(tot, None)
         runs[mode] = dict(E=E, n_obs=n_obs, n_views=n_views, el=el, region_ms=region_ms, total_obs=float(tot.item()),
                           comm={"rccl": "library RCCL communicator: one ncclAllReduce of 81 doubles per step on the "
                                         "compute stream", "torch": "torch.distributed all_reduce (callback)",
@@ -481,7 +508,9 @@ def main():
     if world > 1:
         dist.barrier()
     # whole solves with the set sharded over the ranks: every rank takes part
+    progress("stage timings done")
     sharded = sharded_solves(dev, lib, rank, world, args.views) if (multi and not args.no_solves) else None
+    progress("sharded solves done" if sharded is not None else "no sharded solves")
 
     if rank == 0:
         # the kernel (+ its two tiny reduction launches) over the timed region itself when nothing else

@@ -35,6 +35,20 @@ DBL_EPSILON = float(np.finfo(np.float64).eps)
 _RCCL_COMMS = {}
 
 
+def _all_reduce(t, group, op=None):
+    """dist.all_reduce that is safe for device tensors on a non-NCCL group: gloo's own path for CUDA
+    tensors hangs on this stack when the tensor's stream still has work queued (tools/gloo_cuda_probe.py),
+    so such a tensor is staged through the host (the copy synchronises the stream)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 class Comm:
     """Sum-all-reduce of the small global records; identity for a single rank.
 
@@ -62,14 +76,14 @@ class Comm:
 
     def allreduce(self, t: torch.Tensor):
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce(t, self.group)
         return t
 
     def total(self, x: float, device) -> float:
         if not self.enabled:
             return float(x)
-        t = torch.tensor([float(x)], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        t = torch.tensor([float(x)], dtype=torch.float64)       # a host scalar: no device work to order
+        t = _all_reduce(t.to(device) if dist.get_backend(self.group) == "nccl" else t, self.group)
         return float(t.item())
 
     # -- camcal_comm handles --------------------------------------------------------------
@@ -117,7 +131,7 @@ class Comm:
                 for base, nbytes, t in pools:
                     off = int(buf) - base
                     if 0 <= off and off % 8 == 0 and off + 8 * n <= nbytes:
-                        dist.all_reduce(t.view(-1)[off // 8: off // 8 + n], op=dist.ReduceOp.SUM, group=group)
+                        _all_reduce(t.view(-1)[off // 8: off // 8 + n], group)
                         return 0
                 return -1
             except Exception:          # never unwind through the C frames
