@@ -33,7 +33,7 @@ extern "C" {
 
 int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
                       int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec, double* dK,
-                      double* stats, int32_t* iters, double* scratch, const camcal_comm* comm, void* stream,
+                      double* stats, int32_t* iters, double* Y, double* scratch, const camcal_comm* comm, void* stream,
                       double* cost_out_host, int32_t* iterations_out_host) {
   if (!tiles || !intr || !pose || !mask_host || !rec || !dK || !stats || !scratch || !cost_out_host ||
       !iterations_out_host || crit_type < 1 || crit_type > 3)
@@ -47,14 +47,19 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
         (crit_type == 3 && (change <= eps || it >= max_count)))
       break;
     const double alpha2 = 1.0 - std::pow(0.6, it + 1.0);
-    CAMCAL_DRV_TRY(camcal_normal_eq_fused(CAMCAL_FISHEYE, tiles, intr, pose, 0.0, nullptr, nullptr, nullptr, rec,
-                                          rec + ng, scratch, stream));
+    // with Y (and poses that are re-estimated) the evaluation also leaves every view's first-order
+    // response to the intrinsic step, which moves the warm start of the re-estimation below
+    const bool predict = Y && recompute_extrinsic;
+    if (predict) CAMCAL_DRV_TRY(camcal_normal_eq_fused_response(CAMCAL_FISHEYE, tiles, intr, pose, Y, rec, rec + ng, scratch, stream));
+    else CAMCAL_DRV_TRY(camcal_normal_eq_fused(CAMCAL_FISHEYE, tiles, intr, pose, 0.0, nullptr, nullptr, nullptr, rec,
+                                               rec + ng, scratch, stream));
     CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rec, ng + ns, stream));      // [U|b|cost|C|d] in one message
     CAMCAL_DRV_TRY(camcal_solve_reduced(CAMCAL_FISHEYE, rec, rec + ng, mask_host, 0.0, -alpha2, intr, intr, dK,
                                         stats, stream));
     double st[5];
     CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
     // cv2 re-estimates the poses before it looks at `change`: the launch does not wait for the host
+    if (predict) CAMCAL_DRV_TRY(camcal_pose_predict(CAMCAL_FISHEYE, tiles, Y, dK, -alpha2, iters, pose, stream));
     if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
     CAMCAL_DRV_TRY(rd.end(st, 5));
     // a view whose 6x6 block is not positive definite poisons C, d with NaN; a singular reduced

@@ -344,12 +344,14 @@ __global__ __launch_bounds__(TPB) void k_cross_schur(camcal_tiles t, const doubl
 // Fused normal-equation evaluation: U, b, cost + per-view blocks + Schur
 // complement in one pass over the points.  One tile per wavefront; the wave's
 // partial record [U|b|cost|C|d] goes to scratch[i][tile] (second stage sums).
-template <int MODEL, bool WRITE_BLOCKS, bool PLANAR, bool LOCAL = false>
+// PRED: also leave the view's first-order pose response Y = V^-1 [g | W^T] (lane_pose_response;
+// lam = 0) in Yb for k_pose_predict.
+template <int MODEL, bool WRITE_BLOCKS, bool PLANAR, bool LOCAL = false, bool PRED = false>
 __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const double* __restrict__ intr,
                                                       const double* __restrict__ pose, double lam,
                                                       double* __restrict__ Vb, double* __restrict__ Wb,
                                                       double* __restrict__ gb, double* __restrict__ scratch,
-                                                      int scratch_stride) {
+                                                      int scratch_stride, double* __restrict__ Yb) {
   constexpr int NI = MT<MODEL>::NI;
   constexpr int NG = IntrAcc<MODEL>::NR;
   constexpr int NS = trisz(NI) + NI;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   lane_normal_fused<MODEL, PLANAR, true>(tv, I, p, acc, gacc);       // sums in the local tangent frame
   // C = W V^-1 W^T and d = W V^-1 g do not depend on the pose parametrisation, so the map to
   // Rodrigues coordinates is only needed for stored blocks and for the damping of diag(V)
-  if (!LOCAL && (WRITE_BLOCKS || lam != 0.0)) {
+  if (!LOCAL && (WRITE_BLOCKS || PRED || lam != 0.0)) {
     double Jl[9];
     left_jacobian(p, Jl);
     to_rodrigues_frame<NI>(Jl, acc.V, acc.W, acc.g);
@@ -385,8 +387,16 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   double sacc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
-  if (tv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc);
+  double id[6];
+  if (tv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc, id);
   wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + tile, scratch_stride);
+  if (PRED && tv.n > 0) {
+    lane_pose_response<NI>(acc.V, id, acc.W, acc.g);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Yb[c * S + slot] = acc.g[c];
+#pragma unroll
+    for (int e = 0; e < NI * 6; ++e) Yb[(6 + e) * S + slot] = acc.W[e];
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_finalize_strided(const double* __restrict__ scratch, int n_part, int stride,
@@ -625,7 +635,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
                                                           const double* __restrict__ pose, double lam,
                                                           double* __restrict__ Vb, double* __restrict__ Wb,
                                                           double* __restrict__ gb, double* __restrict__ scratch,
-                                                          int scratch_stride, int local) {
+                                                          int scratch_stride, int local, double* __restrict__ Yb) {
   constexpr int NI = MT<MODEL>::NI;
   constexpr int NG = IntrAcc<MODEL>::NR;
   constexpr int NS = trisz(NI) + NI;
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
   red.template sum<21>(acc.V);
   red.template sum<NI * 6>(acc.W);
   red.template sum<6>(acc.g);
-  if (!local && (Vb || lam != 0.0)) {                 // see k_normal_fused
+  if (!local && (Vb || Yb || lam != 0.0)) {           // see k_normal_fused
     double Jl[9];
     left_jacobian(p, Jl);
     to_rodrigues_frame<NI>(Jl, acc.V, acc.W, acc.g);
@@ -667,8 +677,16 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
   double sacc[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
-  if (gv.gl == 0 && gv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc);
+  double id[6];
+  if (gv.gl == 0 && gv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc, id);
   wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + wave, scratch_stride);
+  if (Yb && gv.gl == 0 && gv.n > 0) {                  // first-order pose response (see k_normal_fused)
+    lane_pose_response<NI>(acc.V, id, acc.W, acc.g);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Yb[c * S + gv.slot] = acc.g[c];
+#pragma unroll
+    for (int e = 0; e < NI * 6; ++e) Yb[(6 + e) * S + gv.slot] = acc.W[e];
+  }
 }
 
 // Evaluations A and B with G lanes per view (the pinhole LM driver's stages).
@@ -840,6 +858,26 @@ __global__ __launch_bounds__(TPB) void k_backsub(camcal_tiles t, const double* _
     for (int c = 0; c < 6; ++c) pose_out[c * S + slot] = out[c];
   }
   wave_reduce_store<2>(acc, scratch, wave);
+}
+
+// First-order move of every pose along the intrinsic step intr_out = intr_in + scale dK of
+// k_solve_reduced (lane_pose_predict): the warm start of the re-estimation that follows.
+// A view whose last refinement took no step (cv2's condition guard, a failed factorisation)
+// stays where it is, as it does in the refinement itself.
+template <int NI>
+__global__ __launch_bounds__(TPB) void k_pose_predict(camcal_tiles t, const double* __restrict__ Yb,
+                                                      const double* __restrict__ dK, double scale,
+                                                      const int32_t* __restrict__ iters, double* __restrict__ pose) {
+  const int64_t S = t.n_slots, slot = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (slot >= S || t.lane_n[slot] <= 0) return;
+  if (iters && iters[slot] == 0) return;
+  double s[NI], p[6];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) s[a] = -scale * dK[a];
+  load_pose(pose, S, slot, p);
+  lane_pose_predict<NI>(Yb, S, slot, s, p);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
 }
 
 // Reduced solve (U' - C) dK = b - d on the free intrinsics, the arithmetic of
@@ -1480,13 +1518,20 @@ int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, c
   return camcal_cross_schur(model, tiles, intr, pose, V, g, lam, W, schur, scratch, stream);
 }
 
-int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
-                     double* V, double* W, double* g, double* glob, double* schur, double* scratch, void* stream) {
+}  // extern "C"
+
+namespace {
+// camcal_normal_eq_fused, optionally (Y != NULL; then no block stores and lam = 0) leaving the
+// views' first-order pose response for camcal_pose_predict
+int normal_eq_fused_impl(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                         double* V, double* W, double* g, double* Y, double* glob, double* schur, double* scratch,
+                         void* stream) {
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !schur || !scratch) return CAMCAL_E_BADARG;
   const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
   if (ng < 0) return ng;
   const bool wb = V && W && g;
   if (!wb && (V || W || g)) return CAMCAL_E_BADARG;
+  if (Y && (wb || lam != 0.0)) return CAMCAL_E_BADARG;
   if (schur != glob + ng) return CAMCAL_E_BADARG;
   const dim3 gr(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
@@ -1497,7 +1542,7 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
     const int np = nt * G;                              // one partial record per wavefront
     const dim3 gg(grid_groups(tiles, G));
     double* redg = scratch + (size_t)(nr + ns) * np;
-#define LAUNCHG(M, GG) hipLaunchKernelGGL((k_normal_fused_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, np, 0)
+#define LAUNCHG(M, GG) hipLaunchKernelGGL((k_normal_fused_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, np, 0, Y)
     if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHG(PINHOLE, 64); else LAUNCHG(PINHOLE, 16); }
     else { if (G == 64) LAUNCHG(FISHEYE, 64); else LAUNCHG(FISHEYE, 16); }
 #undef LAUNCHG
@@ -1511,11 +1556,15 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
   }
   double* red = scratch + (size_t)(nr + ns) * nt;
   if (wb) {
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt)
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt, nullptr)
+    DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
+#undef LAUNCH
+  } else if (Y) {
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, false, P, false, true>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt, Y)
     DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
 #undef LAUNCH
   } else {
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, false, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt)
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, false, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt, nullptr)
     DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
 #undef LAUNCH
   }
@@ -1524,6 +1573,33 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
   HIP_TRY(hipGetLastError());
   if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);
   else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                           double* V, double* W, double* g, double* glob, double* schur, double* scratch, void* stream) {
+  return normal_eq_fused_impl(model, tiles, intr, pose, lam, V, W, g, nullptr, glob, schur, scratch, stream);
+}
+
+int camcal_normal_eq_fused_response(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
+                                    double* Y, double* glob, double* schur, double* scratch, void* stream) {
+  if (!Y) return CAMCAL_E_BADARG;
+  return normal_eq_fused_impl(model, tiles, intr, pose, 0.0, nullptr, nullptr, nullptr, Y, glob, schur, scratch, stream);
+}
+
+int camcal_pose_predict(int model, const camcal_tiles* tiles, const double* Y, const double* dK, double scale,
+                        const int32_t* iters, double* pose, void* stream) {
+  if (!tiles_ok(tiles) || !Y || !dK || !pose) return CAMCAL_E_BADARG;
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  const dim3 gr((unsigned)((tiles->n_slots + TPB - 1) / TPB)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (ni == 9) hipLaunchKernelGGL(k_pose_predict<9>, gr, b, 0, s, *tiles, Y, dK, scale, iters, pose);
+  else hipLaunchKernelGGL(k_pose_predict<8>, gr, b, 0, s, *tiles, Y, dK, scale, iters, pose);
   HIP_TRY(hipGetLastError());
   return 0;
 }

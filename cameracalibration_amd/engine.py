@@ -71,6 +71,10 @@ class Engine:
     def layout(self, value):
         self._layout = value
 
+    #: the fisheye loop starts every pose re-estimation from the first-order predicted pose (camcal_pose_predict);
+    #: False: from the previous pose (the oracle's warm-start path, step for step) -- tests and measurements
+    PREDICT_POSES = True
+
     #: lanes per view of the engines created from now on (camcal_tiles.lanes_per_view: 0 = by size,
     #: 1 / 16 / 64 force a mapping); a plain class default so that tests and tools can pin a mapping
     LANES_PER_VIEW = 0
@@ -158,9 +162,11 @@ class Engine:
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
         NI = self.NI
+        # norms right behind glob1: one all-reduce for a trial point; W right behind g1: together they are
+        # the (NI + 1) * 6 rows of the fisheye loop's pose response Y (that loop stores no blocks)
         sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
                      W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, norms=2, dK=16,
-                     stats=8, view_cost=S, ints=S)   # norms right behind glob1: one all-reduce for a trial point
+                     stats=8, view_cost=S, ints=S)
         pool = torch.zeros(sum(sizes.values()), **f64)
         part, off = {}, 0
         for k, n_k in sizes.items():
@@ -174,6 +180,8 @@ class Engine:
         self.Vs = [part["V0"].view(21, S), part["V1"].view(21, S)]
         self.gs = [part["g0"].view(6, S), part["g1"].view(6, S)]
         self.W = part["W"].view(NI * 6, S)
+        y0 = (part["g1"].data_ptr() - pool.data_ptr()) // 8
+        self.Y = pool[y0:y0 + (NI + 1) * 6 * S].view((NI + 1) * 6, S)      # [V^-1 g | V^-1 W^T], aliases g1 + W
         # [U|b|cost] and [C|d] of buffer 0 share one allocation so a full
         # normal-equation evaluation needs a single all-reduce (self.rec)
         self.rec = part["rec"]
@@ -349,6 +357,7 @@ class Engine:
         self._call("camcal_fisheye_gn", self._tp(), self.intr[0].data_ptr(), self.pose[0].data_ptr(),
                    self._mask_bytes(mask), int(ctype), int(maxc), float(eps), 1 if recompute_extrinsic else 0,
                    self.rec.data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(), self.iters.data_ptr(),
+                   self.Y.data_ptr() if self.PREDICT_POSES else None,
                    self.scratch.data_ptr(), comm, self._stream(), C.byref(cost), C.byref(its))
         return float(cost.value), int(its.value)
 
@@ -388,6 +397,18 @@ class Engine:
                        self.pose[pose_idx].data_ptr(), float(lam), self.V.data_ptr(),
                        self.W.data_ptr() if store_blocks else None, self.g.data_ptr(),
                        self.glob[0].data_ptr(), self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
+
+    def normal_eq_response(self, intr_idx, pose_idx):
+        """The single-pass evaluation (no block stores, lambda = 0) that also leaves every view's first-order
+        pose response in ``self.Y`` (camcal_normal_eq_fused_response; overwrites the second g buffer and W)."""
+        self._call("camcal_normal_eq_fused_response", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), self.Y.data_ptr(), self.glob[0].data_ptr(),
+                   self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
+
+    def pose_predict(self, pose_idx, scale):
+        """Move the poses along the step ``intr += scale * dK`` the last reduced solve took (camcal_pose_predict)."""
+        self._call("camcal_pose_predict", self.model, self._tp(), self.Y.data_ptr(), self.dK.data_ptr(),
+                   float(scale), self.iters.data_ptr(), self.pose[pose_idx].data_ptr(), self._stream())
 
     def reproj_err(self, intr_idx, pose_idx, f32_round=True):
         """Per-view ||proj - corners||_2 / n (caller's view order) and their mean."""

@@ -247,11 +247,17 @@ def gn_fisheye(E, mask, criteria, recompute_extrinsic=True, comm=None, log=None)
            (ctype == 3 and (change <= eps or it >= maxc)):
             break
         alpha2 = 1.0 - 0.6 ** (it + 1.0)
-        E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
+        predict = recompute_extrinsic and E.PREDICT_POSES
+        if predict:
+            E.normal_eq_response(0, 0)
+        else:
+            E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
         comm.allreduce(E.rec)
         E.solve_reduced(0, mask, 0.0, -alpha2, 0, 0)
         st = E.stats[:5].cpu().numpy()
         change = math.sqrt(st[2]) / math.sqrt(st[3])
+        if predict:
+            E.pose_predict(0, -alpha2)
         if recompute_extrinsic:
             E.pose_refine(0, 0, 20, 1e-10)
         it += 1

@@ -409,6 +409,11 @@ def config(name, device="cpu", n_views=None, noise=None, seed=None):
                             FISHEYE_TRUE_K, FISHEYE_TRUE_D, FISHEYE_GUESS_K, FISHEYE_GUESS_D,
                             seed if seed is not None else 5, 0.2 if noise is None else noise, device,
                             name="C5")
+    if name == "C1R":      # ragged pinhole views (the ChArUco partial boards of C3 through the pinhole model)
+        return make_problem("pinhole", n_views or 2000, board_points(9, 7, 50.0), (1920, 1080),
+                            PINHOLE_TRUE_K, PINHOLE_TRUE_D, PINHOLE_GUESS_K, PINHOLE_GUESS_D,
+                            seed if seed is not None else 7, 0.2 if noise is None else noise, device,
+                            ragged=(13, 63), name="C1R")
     if name == "C5P":      # the stress set through the pinhole model (same board and view count as C5)
         return make_problem("pinhole", n_views or 1000000, board_points(11, 8, 25.0), (1920, 1080),
                             PINHOLE_TRUE_K, PINHOLE_TRUE_D, PINHOLE_GUESS_K, PINHOLE_GUESS_D,

@@ -266,6 +266,39 @@ void rig_backsub(int n_cams, int64_t P, const double* Vp, const double* gp, cons
 }
 }  // namespace
 
+namespace {
+template <int MODEL>
+void fused_response(const camcal_tiles* t, const double* intr, const double* pose, double* Y, double* glob,
+                    double* schur_out) {
+  constexpr int NI = MT<MODEL>::NI, NR = IntrAcc<MODEL>::NR, NS = trisz(NI) + NI;
+  const int64_t S = t->n_slots;
+  std::vector<double> tot(NR, 0.0);
+  double sacc[NS];
+  for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int lane = 0; lane < LANES; ++lane) {
+      const int64_t slot = (int64_t)tile * LANES + lane;
+      const LaneTile tv = lane_tile(t, tile, lane);
+      double p[6];
+      load_pose(pose, S, slot, p);
+      ViewAcc<MODEL> acc;
+      IntrAcc<MODEL> gacc;
+      gacc.zero();
+      if (t->planar) lane_normal_fused<MODEL, true>(tv, intr, p, acc, gacc);
+      else lane_normal_fused<MODEL, false>(tv, intr, p, acc, gacc);
+      for (int i = 0; i < NR; ++i) tot[i] += gacc.v[i];
+      if (tv.n <= 0) continue;
+      double id[6];
+      lane_schur_regs<NI>(acc.V, acc.W, acc.g, 0.0, sacc, id);
+      lane_pose_response<NI>(acc.V, id, acc.W, acc.g);
+      for (int c = 0; c < 6; ++c) Y[c * S + slot] = acc.g[c];
+      for (int e = 0; e < NI * 6; ++e) Y[(6 + e) * S + slot] = acc.W[e];
+    }
+  IntrAcc<MODEL>::expand(tot.data(), glob);
+  for (int i = 0; i < NS; ++i) schur_out[i] = sacc[i];
+}
+}  // namespace
+
 extern "C" {
 int camcal_version(void) { return -100; }   // negative: emulator
 
@@ -386,6 +419,29 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* t, const double* intr,
   }
   camcal_view_blocks(model, t, intr, pose, V, W, g, s);
   return camcal_schur(model, t, V, W, g, lam, schur_out, scratch, s);
+}
+int camcal_normal_eq_fused_response(int model, const camcal_tiles* t, const double* intr, const double* pose, double* Y,
+                                    double* glob, double* schur_out, double*, void*) {
+  if (!Y) return CAMCAL_E_BADARG;
+  if (model == 0) fused_response<PINHOLE>(t, intr, pose, Y, glob, schur_out);
+  else fused_response<FISHEYE>(t, intr, pose, Y, glob, schur_out);
+  return 0;
+}
+int camcal_pose_predict(int model, const camcal_tiles* t, const double* Y, const double* dK, double scale,
+                        const int32_t* iters, double* pose, void*) {
+  const int ni = camcal_n_intr(model);
+  if (ni < 0) return ni;
+  const int64_t S = t->n_slots;
+  double s[9];
+  for (int a = 0; a < ni; ++a) s[a] = -scale * dK[a];
+  for (int64_t slot = 0; slot < S; ++slot) {
+    if (t->lane_n[slot] <= 0 || (iters && iters[slot] == 0)) continue;
+    double p[6];
+    load_pose(pose, S, slot, p);
+    if (ni == 9) lane_pose_predict<9>(Y, S, slot, s, p); else lane_pose_predict<8>(Y, S, slot, s, p);
+    for (int c = 0; c < 6; ++c) pose[c * S + slot] = p[c];
+  }
+  return 0;
 }
 int camcal_normal_eq_fused_static(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam,
                                   double* glob, double* schur_out, void* s) {

@@ -460,3 +460,73 @@ def case_extreme_raggedness():
 
 
 ALL.append(case_extreme_raggedness)
+
+
+def case_pose_response_and_predicted_warm_start():
+    """The response stage (camcal_normal_eq_fused_response) and the move it feeds (camcal_pose_predict):
+    (1) same record as the plain single-pass evaluation, Y = V^-1 [g | W^T] against the oracle's blocks;
+    (2) the predicted pose is the joint Gauss-Newton step's pose part (oracle._schur_step) for the intrinsic
+    step taken; a view whose last refinement took no step keeps its pose;
+    (3) a whole solve with the prediction returns what the solve without it returns (the warm-start path the
+    oracle restates step for step), in fewer refinement steps -- every lane mapping."""
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    P = synth.config("C3", n_views=150)
+    objs, imgs = P.as_lists()
+    views = O.Views(objs, imgs)
+    g = P.intr_guess()
+    for lpv in (1, 16, 64):
+        E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
+        E.set_intr(0, g)
+        E.pose_init(0, 0)
+        E.pose_refine(0, 0, 20, 1e-10)
+        poses = E.get_poses(0)
+        E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
+        plain = E.rec.cpu().numpy().copy()
+        E.normal_eq_response(0, 0)
+        rec = E.rec.cpu().numpy().copy()
+        assert np.abs(rec - plain).max() <= 1e-12 * np.abs(plain).max()
+        blk = O.normal_blocks("fisheye", views, g, poses)
+        want = np.linalg.solve(blk["V"], np.concatenate([blk["g"][..., None], blk["W"].transpose(0, 2, 1)], axis=2))
+        Y = E.slots_to_views(E.Y.T).reshape(-1, 9, 6).transpose(0, 2, 1)          # (N, 6, 1 + NI)
+        sc = np.abs(want).max(axis=(0, 1))
+        assert (np.abs(Y - want)[..., 1:].max(axis=(0, 1)) < 1e-8 * sc[1:]).all()
+        # at refined poses V^-1 g is the (vanishing) next Gauss-Newton step: compare on the scale of the poses
+        assert np.abs(Y - want)[..., 0].max() < 1e-12 * np.abs(poses).max()
+        mask = np.ones(8, dtype=bool)
+        a2 = 0.4
+        E.solve_reduced(0, mask, 0.0, -a2, 0, 1)
+        dK = E.dK[:8].cpu().numpy()
+        it = E.iters.clone()
+        frozen = int(E.layout["slot_view"][3])                        # pretend this view's refinement took no step
+        E.iters[3] = 0
+        E.pose_predict(0, -a2)
+        E.iters.copy_(it)
+        got = E.get_poses(0)
+        d = want[..., 0] - np.einsum("bij,j->bi", want[..., 1:], a2 * dK)
+        keep = np.arange(P.n_views) != frozen
+        assert np.array_equal(got[frozen], poses[frozen])
+        assert np.abs(got[keep] - (poses - d)[keep]).max() < 1e-9
+        del E
+    res = []
+    for pred in (False, True):
+        for lpv in ((0,) if not pred else (0, 1, 16, 64)):
+            Engine.PREDICT_POSES, Engine.LANES_PER_VIEW = pred, lpv
+            try:
+                info = {}
+                r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=FE,
+                                         criteria=(3, 1000, 1e-6), _info=info)
+            finally:
+                Engine.PREDICT_POSES, Engine.LANES_PER_VIEW = True, 0
+            res.append((r, info["iters"], float(info["engine"].iters.double().sum().item())))
+    (a, ia, sa) = res[0]
+    for (b, ib, sb) in res[1:]:
+        assert ia == ib and abs(a[0] - b[0]) < 1e-11
+        assert np.allclose(a[1], b[1], rtol=1e-11) and np.allclose(a[2], b[2], rtol=1e-8, atol=1e-13)
+        assert np.allclose(np.hstack(a[3]), np.hstack(b[3]), atol=1e-9)
+        assert np.allclose(np.hstack(a[4]), np.hstack(b[4]), atol=1e-7)
+        assert sb < sa                                               # the last re-estimation alone needs fewer steps
+
+
+ALL.append(case_pose_response_and_predicted_warm_start)

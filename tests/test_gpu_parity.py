@@ -51,7 +51,8 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("name,model,mid,nv", [("C1", "pinhole", 0, 20), ("C2", "fisheye", 1, 500),
-                                               ("C3", "fisheye", 1, 700), ("C3", "fisheye", 1, 1)])
+                                               ("C3", "fisheye", 1, 700), ("C3", "fisheye", 1, 1),
+                                               ("C1R", "pinhole", 0, 700)])
 def test_normal_equation_stages_match_oracle(dev, name, model, mid, nv, mapping):
     P = synth.config(name, n_views=nv)
     objs, imgs = P.as_lists()
@@ -202,6 +203,35 @@ def test_config3_ragged_subsample_vs_oracle(dev, mapping):
     assert abs(r[0] - o[0]) < 1e-9 and np.allclose(r[1], o[1], rtol=1e-9) and np.allclose(r[2], o[2], rtol=1e-6, atol=1e-11)
 
 
+_PINHOLE_RAGGED = {}
+
+
+def _pinhole_ragged_oracle():
+    """2000 ragged pinhole views through the oracle's Schur-eliminated CvLevMarq, once per session."""
+    if not _PINHOLE_RAGGED:
+        P = synth.config("C1R", n_views=2000)
+        objs, imgs = P.as_lists()
+        o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=1, criteria=CRIT, solver="schur")
+        _PINHOLE_RAGGED.update(P=P, objs=objs, imgs=imgs, o=o)
+    return _PINHOLE_RAGGED
+
+
+def test_config1_ragged_pinhole_2000_views_vs_oracle(dev, mapping):
+    """The pinhole twin of the C3 sub-sample test: cv2.calibrateCamera as camera_calib.py:153-156 calls it,
+    on 2000 ragged views (32 tiles, every lane mapping) against the oracle's CvLevMarq on the eliminated
+    system -- same accepted steps, same answer."""
+    c = _pinhole_ragged_oracle()
+    P, o = c["P"], c["o"]
+    info = {}
+    K, D = P.K_guess.copy(), P.D_guess.copy()
+    r = cc.calibrateCamera(c["objs"], c["imgs"], P.image_size, K, D, flags=cc.CALIB_USE_INTRINSIC_GUESS, criteria=CRIT,
+                           _info=info)
+    assert info["iters"] == o[5]["iters"] and abs(r[0] - o[0]) < 1e-9
+    assert np.allclose(K, o[1], rtol=1e-8) and np.allclose(D, o[2], rtol=1e-6, atol=1e-10)
+    assert np.allclose(np.hstack(r[3]).T, o[3], atol=1e-7) and np.allclose(np.hstack(r[4]).T, o[4], atol=1e-5)
+    assert np.allclose(K[[0, 1, 0, 1], [0, 1, 2, 2]], P.K_true, rtol=2e-3)
+
+
 def test_library_sequenced_loops_equal_the_python_loops_on_gpu(dev):
     """camcal_fisheye_gn / camcal_pinhole_lm (single rank, default) against the same loops
     sequenced by solver.py (chosen by asking for the iteration log): identical stage calls."""
@@ -220,23 +250,39 @@ def test_library_sequenced_loops_equal_the_python_loops_on_gpu(dev):
 
 
 @pytest.mark.parametrize("nv", [1, 63, 65, 2048, 2049, 28672, 28673])
-def test_automatic_mapping_at_its_size_boundaries(dev, nv):
+@pytest.mark.parametrize("mid", [1, 0], ids=["fisheye", "pinhole"])
+def test_automatic_mapping_at_its_size_boundaries(dev, nv, mid):
     """The mapping chosen by size (64 lanes per view up to 32 tiles, 16 up to 448, one above)
-    against one lane per view, on ragged sets either side of every boundary: the single-pass
-    record, the stored blocks and a pose re-estimation."""
-    P = synth.config("C3", n_views=nv)
+    against one lane per view, on ragged sets either side of every boundary, both models: the
+    single-pass record, the stored blocks, a pose re-estimation and -- the stages the pinhole
+    LM loop is made of (camera_calib.py:153-156) -- evaluation A + B, the stored-block Schur
+    complement and the back-substitution."""
+    P = synth.config("C3" if mid == 1 else "C1R", n_views=nv)
     out = []
     for mode in (1, 0):
-        E = Engine(1, P.view_ptr, P.obj, P.img, dev, lanes_per_view=mode)
+        E = Engine(mid, P.view_ptr, P.obj, P.img, dev, lanes_per_view=mode)
         E.set_intr(0, P.intr_guess())
         E.set_poses(0, P.poses_true.numpy())
         E.normal_eq(0, 0, 1e-3, store_blocks=True, fused=True)
         rec, W = E.rec.cpu().numpy().copy(), E.slots_to_views(E.W.T).copy()
+        E.normal_eq(0, 0, 1e-3)                                        # evaluation A + B
+        rec2 = E.rec.cpu().numpy().copy()
+        E.schur_complement(1e-2)
+        sch = E.schur.cpu().numpy().copy()
+        if nv >= 63:
+            E.solve_reduced(0, np.ones(E.NI, dtype=bool), 1e-2, -1.0, 0, 1)
+            E.backsub(1e-2, 0, 1)
+            back = (E.get_poses(1), E.norms.cpu().numpy().copy())
+        else:
+            back = (np.zeros(1), np.zeros(1))
         E.pose_refine(0, 0, 20, 1e-10)
-        out.append((rec, W, E.get_poses(0), E.slots_to_views(E.iters).copy()))
-    (r1, w1, p1, i1), (r2, w2, p2, i2) = out
+        out.append((rec, W, E.get_poses(0), E.slots_to_views(E.iters).copy(), rec2, sch, back))
+    (r1, w1, p1, i1, q1, s1, b1), (r2, w2, p2, i2, q2, s2, b2) = out
     assert np.abs(r1 - r2).max() <= 1e-11 * np.abs(r1).max()
     assert np.abs(w1 - w2).max() <= 1e-11 * np.abs(w1).max()
+    assert np.abs(q1 - q2).max() <= 1e-11 * np.abs(q1).max() and np.abs(q1 - r1).max() <= 1e-10 * np.abs(r1).max()
+    assert np.abs(s1 - s2).max() <= 1e-10 * np.abs(s1).max()
+    assert np.allclose(b1[0], b2[0], rtol=1e-7, atol=1e-7) and np.allclose(b1[1], b2[1], rtol=1e-7)
     assert np.allclose(p1, p2, rtol=1e-9, atol=1e-9) and (i1 == i2).mean() > 0.98
 
 
@@ -308,6 +354,97 @@ def test_full_size_properties_config3_and_5(dev, fused):
         assert rel(sym(G[:nu], 8), r["U"]) < 1e-11 and rel(G[nu:nu + 8], r["b"]) < 1e-9
         assert rel(sym(G[45:45 + nu], 8), r["C"]) < 1e-10 and rel(G[45 + nu:], r["d"]) < 1e-9
         del E, Es, P, Q
+        torch.cuda.empty_cache()
+
+
+def test_full_size_properties_pinhole_stress_set(dev):
+    """The pinhole evaluation at the 1M-view size bench.py reports it at (C5P: evaluation A + B, the form the
+    LM loop uses, and the single pass): additivity over two halves, the C oracle on a 4000-view sample,
+    the noise level at the true parameters -- the pinhole twin of the test above."""
+    from oracle import cport
+    nv = 1_000_000
+    P = synth.config("C5P", n_views=nv, device=dev)
+    vp = P.view_ptr
+
+    def engine(Q):
+        E = Engine(0, Q.view_ptr, Q.obj, Q.img, dev)
+        E.set_intr(0, P.intr_true())
+        sv = torch.from_numpy(E.layout["slot_view"].astype(np.int64)).to(dev)
+        pose = torch.zeros(6, E.S, dtype=torch.float64, device=dev)
+        pose[5] = 1.0
+        valid = sv >= 0
+        pose[:, valid] = Q.poses_true.to(dev).T[:, sv[valid]]
+        E.pose[0].copy_(pose)
+        return E
+
+    def sub(lo, hi):
+        return synth.Problem(P.model, P.image_size, P.K_true, P.D_true, P.K_guess, P.D_guess, vp[lo:hi + 1] - vp[lo],
+                             P.obj[vp[lo]:vp[hi]], P.img[vp[lo]:vp[hi]], P.poses_true[lo:hi])
+
+    for ne in ({}, dict(store_blocks=False, fused=True)):
+        E = engine(P)
+        E.normal_eq(0, 0, 0.0, **ne)
+        full = E.rec.cpu().numpy().copy()
+        sigma2 = full[E.glob_len - 1] / (2 * P.n_obs)
+        assert abs(sigma2 - 0.04) < 0.04 * 0.01 + 1e-5
+        del E
+        parts = []
+        for lo, hi in ((0, nv // 2), (nv // 2, nv)):
+            Eh = engine(sub(lo, hi))
+            Eh.normal_eq(0, 0, 0.0, **ne)
+            parts.append(Eh.rec.cpu().numpy().copy())
+            del Eh
+        assert np.allclose(parts[0] + parts[1], full, rtol=1e-9, atol=1e-6 * np.abs(full).max())
+        ns = 4000
+        r = cport.normal_eq(0, vp[:ns + 1].copy(), P.obj[:vp[ns]].cpu().numpy(), P.img[:vp[ns]].cpu().numpy(),
+                            P.intr_true(), P.poses_true[:ns].cpu().numpy(), nthreads=8, want_blocks=False)
+        Es = engine(sub(0, ns))
+        Es.normal_eq(0, 0, 0.0, **ne)
+        G = Es.rec.cpu().numpy()
+        nu = 45
+        assert rel(sym(G[:nu], 9), r["U"]) < 1e-11 and rel(G[nu:nu + 9], r["b"]) < 1e-9
+        assert rel(sym(G[55:55 + nu], 9), r["C"]) < 1e-10 and rel(G[55 + nu:], r["d"]) < 1e-9
+        del Es
+        torch.cuda.empty_cache()
+
+
+def test_whole_stress_solves_fisheye_and_pinhole(dev):
+    """The two 1M-view solves bench.py reports (solve_wall_clock.C5_fisheye_1M_views, kernels.C5p_pinhole_1M_views_lm),
+    asserted: rms at the dof-corrected noise level, intrinsics at the truth to the sampling error of 88M
+    observations, and the iteration count of the oracle's run on a 2000-view sample of the same generator (the
+    stopping rule looks at the intrinsic step, which does not depend on the number of views once they are many)."""
+    from cameracalibration_amd import solver
+    for name, mid, nd in (("C5", 1, 4), ("C5P", 0, 5)):
+        Ps = synth.config(name, n_views=2000)
+        os_, is_ = Ps.as_lists()
+        if mid == 1:
+            o = O.fisheye_calibrate(os_, is_, Ps.image_size, Ps.K_guess, Ps.D_guess, flags=FE, criteria=CRIT, solver="schur")
+        else:
+            o = O.calibrate_camera(os_, is_, Ps.image_size, Ps.K_guess, Ps.D_guess, flags=1, criteria=CRIT, solver="schur")
+        P = synth.config(name, n_views=1_000_000, device=dev)
+        E = Engine(mid, P.view_ptr, P.obj, P.img, dev)
+        E.set_intr(0, P.intr_guess())
+        E.pose_init(0, 0)
+        assert int(E.status.abs().sum().item()) == 0
+        E.pose_refine(0, 0, 20, 1e-10)
+        if mid == 1:
+            cost, it = solver.gn_fisheye(E, np.ones(8, dtype=bool), CRIT)
+        else:
+            cost, it = solver.lm_pinhole(E, np.ones(9, dtype=bool), 1000, 1e-6)
+        intr = E.get_intr(0)
+        rms = np.sqrt(cost / P.n_obs)
+        want = 0.2 * np.sqrt((2 * P.n_obs - 6 * P.n_views - E.NI) / P.n_obs)
+        assert abs(rms - want) < 2e-4, (name, rms, want)
+        assert it == o[5]["iters"], (name, it, o[5]["iters"])
+        assert np.allclose(intr[:4], P.K_true, rtol=2e-5), (name, intr[:4])
+        assert np.allclose(intr[4:4 + nd], P.D_true, atol=2e-4 if mid == 1 else 1e-3), (name, intr[4:])
+        # every pose at its per-view optimum: one more refinement pass moves nothing (fisheye: cv2's rule)
+        if mid == 1:
+            before = E.pose[0].clone()
+            E.pose_refine(0, 0, 20, 1e-10)
+            moved = (E.pose[0] - before).abs().max().item()
+            assert moved < 1e-6 and float(E.iters.double().mean().item()) < 1.2
+        del E, P
         torch.cuda.empty_cache()
 
 
