@@ -59,7 +59,7 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
     double st[5];
     CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
     // cv2 re-estimates the poses before it looks at `change`: the launch does not wait for the host
-    if (predict) CAMCAL_DRV_TRY(camcal_pose_predict(CAMCAL_FISHEYE, tiles, Y, dK, -alpha2, iters, pose, stream));
+    if (predict) CAMCAL_DRV_TRY(camcal_pose_predict(CAMCAL_FISHEYE, tiles, Y, dK, -alpha2, iters, 20, pose, stream));
     if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
     CAMCAL_DRV_TRY(rd.end(st, 5));
     // a view whose 6x6 block is not positive definite poisons C, d with NaN; a singular reduced

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(TPB) void k_cross_schur(camcal_tiles t, const doubl
 // Fused normal-equation evaluation: U, b, cost + per-view blocks + Schur
 // complement in one pass over the points.  One tile per wavefront; the wave's
 // partial record [U|b|cost|C|d] goes to scratch[i][tile] (second stage sums).
-// PRED: also leave the view's first-order pose response Y = V^-1 [g | W^T] (lane_pose_response;
+// PRED: also leave the view's first-order pose response Y = V^-1 W^T (lane_pose_response;
 // lam = 0) in Yb for k_pose_predict.
 template <int MODEL, bool WRITE_BLOCKS, bool PLANAR, bool LOCAL = false, bool PRED = false>
 __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const double* __restrict__ intr,
@@ -391,11 +391,9 @@ __global__ __launch_bounds__(TPB) void k_normal_fused(camcal_tiles t, const doub
   if (tv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc, id);
   wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + tile, scratch_stride);
   if (PRED && tv.n > 0) {
-    lane_pose_response<NI>(acc.V, id, acc.W, acc.g);
+    lane_pose_response<NI>(acc.V, id, acc.W);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) Yb[c * S + slot] = acc.g[c];
-#pragma unroll
-    for (int e = 0; e < NI * 6; ++e) Yb[(6 + e) * S + slot] = acc.W[e];
+    for (int e = 0; e < NI * 6; ++e) Yb[e * S + slot] = acc.W[e];
   }
 }
 
@@ -681,11 +679,9 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
   if (gv.gl == 0 && gv.n > 0) lane_schur_regs<NI>(acc.V, acc.W, acc.g, lam, sacc, id);
   wave_scatter_store<NS>(sacc, lane, scratch + (size_t)NG * scratch_stride + wave, scratch_stride);
   if (Yb && gv.gl == 0 && gv.n > 0) {                  // first-order pose response (see k_normal_fused)
-    lane_pose_response<NI>(acc.V, id, acc.W, acc.g);
+    lane_pose_response<NI>(acc.V, id, acc.W);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) Yb[c * S + gv.slot] = acc.g[c];
-#pragma unroll
-    for (int e = 0; e < NI * 6; ++e) Yb[(6 + e) * S + gv.slot] = acc.W[e];
+    for (int e = 0; e < NI * 6; ++e) Yb[e * S + gv.slot] = acc.W[e];
   }
 }
 
@@ -863,14 +859,16 @@ __global__ __launch_bounds__(TPB) void k_backsub(camcal_tiles t, const double* _
 // First-order move of every pose along the intrinsic step intr_out = intr_in + scale dK of
 // k_solve_reduced (lane_pose_predict): the warm start of the re-estimation that follows.
 // A view whose last refinement took no step (cv2's condition guard, a failed factorisation)
-// stays where it is, as it does in the refinement itself.
+// stays where it is, as it does in the refinement itself; so does one that ran into the step
+// cap: it is not at its optimum, where the response is derived.
 template <int NI>
 __global__ __launch_bounds__(TPB) void k_pose_predict(camcal_tiles t, const double* __restrict__ Yb,
                                                       const double* __restrict__ dK, double scale,
-                                                      const int32_t* __restrict__ iters, double* __restrict__ pose) {
+                                                      const int32_t* __restrict__ iters, int cap,
+                                                      double* __restrict__ pose) {
   const int64_t S = t.n_slots, slot = (int64_t)blockIdx.x * TPB + threadIdx.x;
   if (slot >= S || t.lane_n[slot] <= 0) return;
-  if (iters && iters[slot] == 0) return;
+  if (iters && (iters[slot] == 0 || iters[slot] >= cap)) return;
   double s[NI], p[6];
 #pragma unroll
   for (int a = 0; a < NI; ++a) s[a] = -scale * dK[a];
@@ -1592,14 +1590,14 @@ int camcal_normal_eq_fused_response(int model, const camcal_tiles* tiles, const 
 }
 
 int camcal_pose_predict(int model, const camcal_tiles* tiles, const double* Y, const double* dK, double scale,
-                        const int32_t* iters, double* pose, void* stream) {
+                        const int32_t* iters, int cap, double* pose, void* stream) {
   if (!tiles_ok(tiles) || !Y || !dK || !pose) return CAMCAL_E_BADARG;
   const int ni = camcal_n_intr(model);
   if (ni < 0) return ni;
   const dim3 gr((unsigned)((tiles->n_slots + TPB - 1) / TPB)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
-  if (ni == 9) hipLaunchKernelGGL(k_pose_predict<9>, gr, b, 0, s, *tiles, Y, dK, scale, iters, pose);
-  else hipLaunchKernelGGL(k_pose_predict<8>, gr, b, 0, s, *tiles, Y, dK, scale, iters, pose);
+  if (ni == 9) hipLaunchKernelGGL(k_pose_predict<9>, gr, b, 0, s, *tiles, Y, dK, scale, iters, cap, pose);
+  else hipLaunchKernelGGL(k_pose_predict<8>, gr, b, 0, s, *tiles, Y, dK, scale, iters, cap, pose);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -128,34 +128,33 @@ CC_HD void lane_schur_regs(double V[21], double* W, double g[6], double lam, dou
 
 // First-order response of a view's pose to an intrinsic step.  For intrinsics moved by -s
 // (K <- K - s) the pose that minimises the view's linearised residual is
-//   pose - d,   V d = g - W^T s   (the back-substitution row of the joint normal equations),
-// so with  Y = V^-1 [g | W_0^T ... W_{NI-1}^T]  (6 x (NI + 1), Rodrigues frame)
-//   d = Y_g - sum_a Y_a s_a.
+//   pose - d,   V d = g - W^T s   (the back-substitution row of the joint normal equations);
+// at a pose that is its view's optimum g = 0, so with  Y = V^-1 W^T  (6 x NI, Rodrigues frame)
+//   pose_new = pose + Y s.
 // cv::fisheye::calibrate re-estimates every pose after its intrinsic step
 // (CALIB_RECOMPUTE_EXTRINSIC, camera_calib.py:76); moving the warm start of that refinement
-// along d leaves an O(|s|^2) error instead of O(|s|) for ComputeExtrinsicRefine to remove.
+// along Y s leaves ComputeExtrinsicRefine one Gauss-Newton step less to take.  (The V^-1 g
+// term is left out on purpose: it vanishes for a converged view and would be an extra,
+// unrequested Gauss-Newton step for one that ran into the step cap.)
 // In: the factor and the forward-substituted columns lane_schur_regs leaves (lam = 0).
 template <int NI>
-CC_HD void lane_pose_response(const double U[21], const double id[6], double* W, double g[6]) {
-  chol6_bwd(U, id, g);
+CC_HD void lane_pose_response(const double U[21], const double id[6], double* W) {
   CC_UNROLL
   for (int a = 0; a < NI; ++a) chol6_bwd(U, id, W + a * 6);
 }
-// Yb: [(NI + 1) * 6][S] component-major, g first: Yb[c * S + slot] = (V^-1 g)_c,
-// Yb[(6 + a * 6 + c) * S + slot] = (V^-1 W_a^T)_c.  s[a] = the intrinsic step (K_new = K - s).
+// Yb: [NI * 6][S] component-major like W: Yb[(a * 6 + c) * S + slot] = (V^-1 W_a^T)_c.
+// s[a] = the intrinsic step (K_new = K - s).
 template <int NI>
 CC_HD void lane_pose_predict(const double* Yb, long long S, long long slot, const double* s, double pose[6]) {
-  double d[6];
-  CC_UNROLL
-  for (int c = 0; c < 6; ++c) d[c] = Yb[c * S + slot];
+  double d[6] = {0, 0, 0, 0, 0, 0};
   CC_UNROLL
   for (int a = 0; a < NI; ++a) {
     const double sa = s[a];
     CC_UNROLL
-    for (int c = 0; c < 6; ++c) d[c] = fma(-Yb[(6 + a * 6 + c) * S + slot], sa, d[c]);
+    for (int c = 0; c < 6; ++c) d[c] = fma(Yb[(a * 6 + c) * S + slot], sa, d[c]);
   }
   CC_UNROLL
-  for (int c = 0; c < 6; ++c) pose[c] -= d[c];
+  for (int c = 0; c < 6; ++c) pose[c] += d[c];
 }
 
 // ---------------------------------------------------------------------------

@@ -162,8 +162,7 @@ class Engine:
         dev = self.device
         f64 = dict(dtype=torch.float64, device=dev)
         NI = self.NI
-        # norms right behind glob1: one all-reduce for a trial point; W right behind g1: together they are
-        # the (NI + 1) * 6 rows of the fisheye loop's pose response Y (that loop stores no blocks)
+        # norms right behind glob1: one all-reduce for a trial point
         sizes = dict(intr0=16, intr1=16, pose0=6 * S, pose1=6 * S, V0=21 * S, V1=21 * S, g0=6 * S, g1=6 * S,
                      W=NI * 6 * S, rec=self.glob_len + self.schur_len, glob1=self.glob_len, norms=2, dK=16,
                      stats=8, view_cost=S, ints=S)
@@ -180,8 +179,7 @@ class Engine:
         self.Vs = [part["V0"].view(21, S), part["V1"].view(21, S)]
         self.gs = [part["g0"].view(6, S), part["g1"].view(6, S)]
         self.W = part["W"].view(NI * 6, S)
-        y0 = (part["g1"].data_ptr() - pool.data_ptr()) // 8
-        self.Y = pool[y0:y0 + (NI + 1) * 6 * S].view((NI + 1) * 6, S)      # [V^-1 g | V^-1 W^T], aliases g1 + W
+        self.Y = self.W          # the fisheye loop's pose response V^-1 W^T: that loop stores no blocks
         # [U|b|cost] and [C|d] of buffer 0 share one allocation so a full
         # normal-equation evaluation needs a single all-reduce (self.rec)
         self.rec = part["rec"]
@@ -400,7 +398,7 @@ class Engine:
 
     def normal_eq_response(self, intr_idx, pose_idx):
         """The single-pass evaluation (no block stores, lambda = 0) that also leaves every view's first-order
-        pose response in ``self.Y`` (camcal_normal_eq_fused_response; overwrites the second g buffer and W)."""
+        pose response in ``self.Y`` (camcal_normal_eq_fused_response; Y shares the W buffer)."""
         self._call("camcal_normal_eq_fused_response", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
                    self.pose[pose_idx].data_ptr(), self.Y.data_ptr(), self.glob[0].data_ptr(),
                    self.schur.data_ptr(), self.scratch.data_ptr(), self._stream())
@@ -408,7 +406,7 @@ class Engine:
     def pose_predict(self, pose_idx, scale):
         """Move the poses along the step ``intr += scale * dK`` the last reduced solve took (camcal_pose_predict)."""
         self._call("camcal_pose_predict", self.model, self._tp(), self.Y.data_ptr(), self.dK.data_ptr(),
-                   float(scale), self.iters.data_ptr(), self.pose[pose_idx].data_ptr(), self._stream())
+                   float(scale), self.iters.data_ptr(), 20, self.pose[pose_idx].data_ptr(), self._stream())
 
     def reproj_err(self, intr_idx, pose_idx, f32_round=True):
         """Per-view ||proj - corners||_2 / n (caller's view order) and their mean."""

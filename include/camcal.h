@@ -187,11 +187,11 @@ int camcal_normal_eq_fused(int model, const camcal_tiles* tiles, const double* i
                            double* glob, double* schur, double* scratch, void* stream);
 
 /* camcal_normal_eq_fused (no block stores, lam = 0) that also leaves every view's first-order
- * pose response to an intrinsic step in Y [(NI + 1) * 6][n_slots], component-major:
- *   Y[c * n_slots + s]               = (V^-1 g)_c
- *   Y[(6 + a * 6 + c) * n_slots + s] = (V^-1 W_a^T)_c        (Rodrigues coordinates)
- * i.e. the back-substitution row d = V^-1 (g - W^T dK) of the joint normal equations, kept so
- * that camcal_pose_predict can apply it once the reduced solve has produced dK.  No OpenCV
+ * pose response to an intrinsic step in Y [NI * 6][n_slots], component-major like W:
+ *   Y[(a * 6 + c) * n_slots + s] = (V^-1 W_a^T)_c        (Rodrigues coordinates)
+ * i.e. the back-substitution row d = V^-1 (g - W^T dK) of the joint normal equations at a pose
+ * that is its view's optimum (g = 0), kept so that camcal_pose_predict can apply it once the
+ * reduced solve has produced dK.  No OpenCV
  * counterpart as a stage: cv::fisheye::calibrate restarts every pose from InitExtrinsics
  * after its intrinsic step (camera_calib.py:74-77 always passes CALIB_RECOMPUTE_EXTRINSIC);
  * this library warm-starts the same ComputeExtrinsicRefine, and the response moves that warm
@@ -201,13 +201,13 @@ int camcal_normal_eq_fused_response(int model, const camcal_tiles* tiles, const 
                                     const double* pose, double* Y, double* glob, double* schur,
                                     double* scratch, void* stream);
 
-/* pose <- pose - (V^-1 g - V^-1 W^T s) for the intrinsic step intr_out = intr_in + scale * dK
- * that camcal_solve_reduced took (s = -scale * dK), from the Y of
- * camcal_normal_eq_fused_response at intr_in.  iters (optional): the step counts of the last
- * camcal_pose_refine; a view that took none (cv2's cond(J) guard, a failed factorisation)
- * keeps its pose, as it does in the refinement. */
+/* pose <- pose + V^-1 W^T s for the intrinsic step intr_out = intr_in + scale * dK that
+ * camcal_solve_reduced took (s = -scale * dK), from the Y of camcal_normal_eq_fused_response
+ * at intr_in.  iters (optional): the step counts of the last camcal_pose_refine; a view that
+ * took none (cv2's cond(J) guard, a failed factorisation) or ran into the cap of `cap` steps
+ * (it is not at its optimum) keeps its pose and is refined from there as before. */
 int camcal_pose_predict(int model, const camcal_tiles* tiles, const double* Y, const double* dK,
-                        double scale, const int32_t* iters, double* pose, void* stream);
+                        double scale, const int32_t* iters, int cap, double* pose, void* stream);
 
 /* The evaluation of camcal_normal_eq_fused (no block stores: V = W = g = NULL) for callers
  * that cannot allocate device memory or carry a workspace: code under HIP graph capture,
@@ -267,7 +267,7 @@ int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void*
  * with recompute_extrinsic (CALIB_RECOMPUTE_EXTRINSIC) -- re-estimation of every pose.
  * intr, pose: starting point in, result out.  rec: camcal_glob_len + camcal_schur_len
  * doubles, dK 16, stats 8, iters [n_slots] (may be NULL), scratch camcal_scratch_len.
- * Y: 54 * n_slots doubles of workspace (camcal_normal_eq_fused_response) or NULL; with it
+ * Y: 48 * n_slots doubles of workspace (camcal_normal_eq_fused_response) or NULL; with it
  * every re-estimation starts from the first-order predicted pose (camcal_pose_predict)
  * instead of the previous one -- same results to the refinement's tolerance, about a third
  * fewer Gauss-Newton steps per view.

