@@ -3,7 +3,7 @@
 The product path has exactly one implementation: the HIP library built from
 ``csrc/camcal_kernels.hip``.  :func:`load` raises if it is missing -- there is
 no CPU fallback.  Tests may pass an explicit ``path`` (the CPU lane emulator
-under ``tests/hostemu``) to exercise the host logic without a GPU.
+of the test tree) to exercise the host logic without a GPU.
 """
 from __future__ import annotations
 
@@ -75,6 +75,7 @@ _SIGNATURES = {
     "camcal_rccl_unique_id": (C.c_int, [_P]),
     "camcal_comm_rccl_create": (C.c_int, [_P, _I, _I, C.POINTER(_P)]),
     "camcal_comm_destroy": (C.c_int, [_P]),
+    "camcal_comm_size": (C.c_int, [_P]),
     "camcal_comm_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
     "camcal_normal_eq_fused_response": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_pose_predict": (C.c_int, [_I, _TP, _P, _P, _D, _P, _I, _P, _P]),
@@ -106,7 +107,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-E_NUMERIC, E_COMM = -4, -5
+E_NUMERIC, E_COMM, E_DISJOINT, E_PEER = -4, -5, -6, -7
 
 
 class CamcalError(RuntimeError):
@@ -115,6 +116,14 @@ class CamcalError(RuntimeError):
 
 class CamcalNumericError(CamcalError):
     """CAMCAL_E_NUMERIC: a solver loop met a singular system or a non-finite cost."""
+
+
+class CamcalStatus(CamcalError):
+    """A call returned a CAMCAL_E_* / hipError_t status; ``code`` holds it."""
+
+    def __init__(self, msg, code):
+        super().__init__(msg)
+        self.code = int(code)
 
 
 class CamcalLib:
@@ -137,8 +146,8 @@ class CamcalLib:
         if rc == E_NUMERIC:
             raise CamcalNumericError(f"{what}: singular system or non-finite cost (degenerate views?)")
         if rc != 0:
-            raise CamcalError(f"{what} failed with status {rc}"
-                              + (" (hipError_t)" if rc > 0 else " (CAMCAL_E_*)"))
+            raise CamcalStatus(f"{what} failed with status {rc}"
+                               + (" (hipError_t)" if rc > 0 else " (CAMCAL_E_*)"), rc)
 
 
 _cached = None

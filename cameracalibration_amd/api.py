@@ -84,20 +84,10 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-_test_backend = None
-
-
-def _set_test_backend(lib, device):
-    """Tests only: route every call of this package to the given library (the
-    CPU lane emulator of tests/hostemu) and device; ``None, None`` restores."""
-    global _test_backend
-    _test_backend = None if lib is None else (lib, torch.device(device))
-
-
 def _resolve():
-    """(lib or None for the HIP build, device) of a call."""
-    if _test_backend is not None:
-        return _test_backend
+    """(library, device) of a call: always the HIP build (``None`` = _lib.load()) on a ROCm device.
+    The package holds no other route; the CPU tier of the tests replaces this function from the
+    outside (tests/conftest.py: use_emulator) to run the host logic on its lane emulator."""
     return None, _device()
 
 
@@ -118,7 +108,8 @@ def _gather_views(object_points, image_points, min_points=4):
             cat_i = np.concatenate(image_points, axis=0)
             # rows per view from the leading dimensions when a row is one point (len() is much
             # cheaper than .size over a list), else from the sizes
-            if cat_o.ndim > 1 and cat_i.ndim > 1 and cat_o[0].size == 3 and cat_i[0].size == 2:
+            if cat_o.ndim > 1 and cat_i.ndim > 1 and int(np.prod(cat_o.shape[1:])) == 3 \
+                    and int(np.prod(cat_i.shape[1:])) == 2:
                 counts = np.array(list(map(len, object_points)), dtype=np.int64)
                 ci = np.array(list(map(len, image_points)), dtype=np.int64)
                 so, si = counts * 3, ci * 2
@@ -185,15 +176,20 @@ def _poses_to_tuples(poses):
     return rvecs, tvecs
 
 
-def _raise_degenerate(E, cause=None, bad=None):
+def _raise_degenerate(E, cause=None, bad=None, comm=None, dev=None):
     """cv2 has no usable answer for a view whose points are collinear or coincident (its
     homography / SVD pose start is garbage and the solve returns non-finite values for the
-    caller's checkRange); this module raises instead and names the views."""
+    caller's checkRange); this module raises instead and names the views.  With a
+    communicator the decision is collective (the count of such views is summed over the
+    ranks first): every rank raises or none does, so none is left alone in a later collective."""
     if bad is None:
         bad = np.flatnonzero(E.slots_to_views(E.status) != 0)
+    n_all = bad.size if comm is None else int(round(comm.total(bad.size, dev)))
     if bad.size:
         raise error("degenerate view(s) %s: the pose initialisation failed (collinear / coincident points); "
                     "remove them" % (bad[:16].tolist(),))
+    if n_all:
+        raise error("degenerate view(s) on another rank: the pose initialisation failed there")
     if cause is not None:
         raise error("the solve met a singular system or a non-finite cost (%s)" % cause)
 
@@ -264,7 +260,7 @@ def _solve_pinhole(E, dev, D, mask, maxc, eps, comm, _info, cameraMatrix, distCo
         _raise_degenerate(E, exc)
         raise
     intr, poses, bad = E.read_solution()
-    _raise_degenerate(E, bad=bad)
+    _raise_degenerate(E, bad=bad, comm=comm, dev=dev)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(err / n_total))
     Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])
@@ -295,8 +291,7 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     ``iters``, ``engine`` and ``log`` (the per-iteration records, collected only
     when the dict holds ``log=True``: asking for them keeps the loop in
     solver.py instead of the library); ``_comm`` -- a solver.Comm for a
-    multi-rank solve.  (The tests' CPU lane emulator comes in through the
-    module's one hook, ``_set_test_backend``, not through the call.)
+    multi-rank solve.
     """
     flags = int(flags)
     D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
@@ -353,7 +348,7 @@ def _solve_fisheye(E, dev, mask, flags, criteria, comm, _info, K, D):
         _raise_degenerate(E, exc)
         raise
     intr, poses, bad = E.read_solution()
-    _raise_degenerate(E, bad=bad)
+    _raise_degenerate(E, bad=bad, comm=comm, dev=dev)
     n_total = comm.total(E.n_obs, dev)
     rms = float(np.sqrt(cost / n_total))
     Kout = np.array([[intr[0], 0.0, intr[2]], [0.0, intr[1], intr[3]], [0.0, 0.0, 1.0]])

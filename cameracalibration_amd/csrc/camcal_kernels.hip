@@ -7,7 +7,9 @@
 // the tile's partial sums at the end of the reducing kernels (halving
 // exchanges, WaveReduceScatter), followed by a fixed-order second stage
 // (deterministic sums).  Small view sets give a view 16 or 64 lanes instead
-// (group_lanes).  FP64 VALU bound; no MFMA, no LDS tiling.
+// (group_lanes).  The single-camera kernels are FP64-VALU bound and use no MFMA (fp64 matrix
+// rate = vector rate on this part, reduced system <= 9 x 9); the rig path's one dense
+// contraction does run on v_mfma_f64_16x16x4 (camcal_rig_kernels.h, k_rig_gram).
 //
 // Replaces the arithmetic the reference delegates to cv2.calibrateCamera /
 // cv2.fisheye.calibrate (server/aruco/camera_calib.py:74-77,153-156).
@@ -1208,18 +1210,9 @@ inline int grid_persistent(const camcal_tiles* t) {
 // Lanes per view for this set: 1 (large sets: a lane walks its view), or 16 / 64 for
 // small planar sets.  The partial records of a grouped launch are one per wavefront
 // (n_tiles * G of them) and must fit the scratch every caller holds (camcal_scratch_len).
-constexpr int GROUP64_MAX_TILES = 32;      // <= 2048 views: one wavefront per view
-constexpr int GROUP16_MAX_TILES = 448;     // <= 28672 views: four views per wavefront (tools/gpu_lanes.py: ahead of one lane per
-                                           // view up to ~30 000 views, full boards and ragged ones alike; 2.4 vs 3.9 ms at 12 000)
 static_assert(GROUP64_MAX_TILES * 64 <= PARTIAL_STRIDE && GROUP16_MAX_TILES * 16 <= PARTIAL_STRIDE,
               "grouped launches write one partial record per wavefront into PARTIAL_STRIDE-strided scratch");
-inline int group_lanes(const camcal_tiles* t) {
-  const int want = t->lanes_per_view;      // 0: by size
-  if (!t->planar || want == 1) return 1;
-  if (want == 64) return t->n_tiles <= GROUP64_MAX_TILES ? 64 : 1;
-  if (want == 16) return t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
-  return t->n_tiles <= GROUP64_MAX_TILES ? 64 : t->n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
-}
+inline int group_lanes(const camcal_tiles* t) { return lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view); }
 inline int grid_groups(const camcal_tiles* t, int G) { return (int)((t->n_slots * G + TPB - 1) / TPB); }
 
 }  // namespace
@@ -1230,7 +1223,6 @@ inline int grid_groups(const camcal_tiles* t, int G) { return (int)((t->n_slots 
 // [NR + NS rows][partials] + the reduced values, for callers that cannot allocate.  The name
 // is a host-side stand-in for a per-device array: host code only ever uses the address
 // hipGetSymbolAddress returns for the current device (static_scratch_ptr).
-constexpr int STATIC_MAX_PARTIALS = 16384;        // tiles (one lane per view) or wavefronts (grouped sets)
 constexpr int STATIC_ROWS = 109;                  // pinhole: 55 + 54 (fisheye 37 + 44)
 constexpr size_t STATIC_SCRATCH_DOUBLES = (size_t)STATIC_ROWS * STATIC_MAX_PARTIALS + 2 * MAX_NV;
 static __device__ __align__(256) double static_scratch[STATIC_SCRATCH_DOUBLES];
@@ -1767,6 +1759,7 @@ struct RcclApi {
   int (*comm_init_rank)(void** comm, int nranks, RcclUniqueId id, int rank) = nullptr;
   int (*all_reduce)(const void*, void*, size_t, int, int, void* comm, hipStream_t) = nullptr;
   int (*comm_destroy)(void* comm) = nullptr;
+  int (*comm_count)(const void* comm, int* count) = nullptr;
   bool ok = false;
 };
 std::mutex g_rccl_mu;
@@ -1782,6 +1775,7 @@ const RcclApi* rccl_api() {
     g_rccl.comm_init_rank = (decltype(g_rccl.comm_init_rank))dlsym(h, "ncclCommInitRank");
     g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(h, "ncclAllReduce");
     g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.comm_count = (decltype(g_rccl.comm_count))dlsym(h, "ncclCommCount");
     g_rccl.ok = g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.all_reduce && g_rccl.comm_destroy;
   }
   return g_rccl.ok ? &g_rccl : nullptr;
@@ -1789,6 +1783,7 @@ const RcclApi* rccl_api() {
 struct RcclComm {
   camcal_comm base;        // first member: the handle handed out
   void* nccl = nullptr;
+  int nranks = 0;          // ncclCommCount at creation
 };
 int rccl_allreduce_sum(void* ctx, double* buf, int64_t n, void* stream) {
   const RcclComm* c = (const RcclComm*)ctx;
@@ -1817,6 +1812,8 @@ int camcal_comm_rccl_create(const void* id128_host, int rank, int world_size, ca
     delete c;
     return CAMCAL_E_COMM;
   }
+  // what RCCL itself says the communicator spans (not what the caller asked for)
+  if (!api->comm_count || api->comm_count(c->nccl, &c->nranks) != 0) c->nranks = -1;
   c->base.allreduce_sum = rccl_allreduce_sum;
   c->base.ctx = c;
   *comm_out = &c->base;
@@ -1830,6 +1827,12 @@ int camcal_comm_destroy(camcal_comm* comm) {
   if (api && c->nccl) api->comm_destroy(c->nccl);
   delete c;
   return 0;
+}
+int camcal_comm_size(const camcal_comm* comm) {
+  if (!comm) return 1;
+  if (comm->allreduce_sum != rccl_allreduce_sum) return CAMCAL_E_BADARG;
+  const int n = ((const RcclComm*)comm->ctx)->nranks;
+  return n > 0 ? n : CAMCAL_E_COMM;
 }
 int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void* stream) {
   if (!comm) return 0;

@@ -751,6 +751,23 @@ CC_HD int lane_pose_init(const LaneTile& tv, const double* intr, double pose[6])
 // The eliminated form of CvLevMarq::step / fisheye::calibrate's solve(JJ2, ex3).
 // ws: REDUCED_WS doubles of working storage (the kernel passes LDS: the pivoting makes
 // every index dynamic, and private arrays indexed dynamically live in scratch memory).
+// Lanes per view of a set (camcal_tiles.lanes_per_view: 0 = by size) and the partial records a
+// single-pass launch writes: shared by the HIP build and the tests' emulator so that both
+// reject the same sets in camcal_normal_eq_fused_static.
+constexpr int GROUP64_MAX_TILES = 32;      // <= 2048 views: one wavefront per view
+constexpr int GROUP16_MAX_TILES = 448;     // <= 28672 views: four views per wavefront (tools/gpu_lanes.py: ahead of one lane per
+                                           // view up to ~30 000 views, full boards and ragged ones alike; 2.4 vs 3.9 ms at 12 000)
+constexpr int STATIC_MAX_PARTIALS = 16384; // tiles (one lane per view) or wavefronts (grouped sets)
+inline int lanes_per_view_of(int n_tiles, int planar, int want) {
+  if (!planar || want == 1) return 1;
+  if (want == 64) return n_tiles <= GROUP64_MAX_TILES ? 64 : 1;
+  if (want == 16) return n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
+  return n_tiles <= GROUP64_MAX_TILES ? 64 : n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
+}
+inline long long static_partials(int n_tiles, int planar, int want) {
+  return (long long)n_tiles * lanes_per_view_of(n_tiles, planar, want);
+}
+
 constexpr int REDUCED_WS = 128;
 #if defined(__HIPCC__)
 __host__ __device__

@@ -47,13 +47,25 @@ int camcal_rig_init(const camcal_rig* rig, const camcal_comm* comm, void* stream
     if (rc_cam == 0) rc_cam = camcal_pose_refine(model, &k.tiles, rig->intr[0] + c * 16, k.pose, 20, 1e-10, nullptr, side[c]);
   }
   CAMCAL_DRV_TRY(camcal_join_streams(stream, nC, side));      // also after a failed launch: nothing stays forked
-  if (rc_cam) return rc_cam;
+  if (rc_cam && !comm) return rc_cam;
+  // With a communicator a rank-local failure must not leave the other ranks waiting in the
+  // all-reduce below: the number of failed ranks travels with the pair sums (one more double)
+  // and every rank takes the same decision afterwards.
+  const int n_sums = nC * nC * 13;
   double* sums_dev = nullptr;
-  CAMCAL_DRV_TRY(rig_pair_sums(rig, &sums_dev, stream));
-  CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, sums_dev, (int64_t)nC * nC * 13, stream));
-  double sums[CAMCAL_RIG_MAX_CAMS * CAMCAL_RIG_MAX_CAMS * 13], ext[CAMCAL_RIG_MAX_CAMS * 6];
-  CAMCAL_DRV_TRY(camcal_read_sync(sums, sums_dev, nC * nC * 13, stream));
-  if (!camcal::righost::ext_from_pair_sums(nC, sums, ext)) return CAMCAL_E_BADARG;   // a camera shares no pose
+  int rc_local = rc_cam;
+  if (rc_local == 0) rc_local = rig_pair_sums(rig, &sums_dev, stream);
+  if (!sums_dev) sums_dev = rig->scratch;                     // where rig_pair_sums puts them
+  const double failed = rc_local ? 1.0 : 0.0;
+  if (comm) CAMCAL_DRV_TRY(camcal_write_sync(sums_dev + n_sums, &failed, 1, stream));
+  else if (rc_local) return rc_local;
+  CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, sums_dev, (int64_t)n_sums + (comm ? 1 : 0), stream));
+  double sums[CAMCAL_RIG_MAX_CAMS * CAMCAL_RIG_MAX_CAMS * 13 + 1], ext[CAMCAL_RIG_MAX_CAMS * 6];
+  sums[n_sums] = 0.0;
+  CAMCAL_DRV_TRY(camcal_read_sync(sums, sums_dev, n_sums + (comm ? 1 : 0), stream));
+  if (rc_local) return rc_local;
+  if (sums[n_sums] != 0.0) return CAMCAL_E_PEER;
+  if (!camcal::righost::ext_from_pair_sums(nC, sums, ext)) return CAMCAL_E_DISJOINT;   // a camera shares no pose (same sums on every rank)
   CAMCAL_DRV_TRY(camcal_write_sync(rig->ext[0], ext, nC * 6, stream));
   return rig_init_poses(rig, stream);
 }

@@ -24,7 +24,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .api import _gather_views, _resolve, error
+from . import api as _api
+from .api import _gather_views, error
 from .engine import Engine
 
 NORM_L2 = 4
@@ -36,7 +37,7 @@ SOLVEPNP_ITERATIVE = 0
 
 
 def _ctx():
-    lib, dev = _resolve()
+    lib, dev = _api._resolve()
     lib = lib if lib is not None else _lib.load()
     if dev.type != "cuda" and not lib.is_emulator:
         raise _lib.CamcalError("the HIP library needs a cuda (ROCm) device; there is no CPU path")
@@ -140,7 +141,7 @@ def checkRange(a):
 def reproj_errors(model, objectPoints, imagePoints, rvecs, tvecs, K, D, f32_round=True):
     """The per-view acceptance numbers ``norm(project(board_i), corners_i) / n_i``
     of a whole list of views in one launch.  Returns (errors (N,), their mean)."""
-    lib, dev = _resolve()
+    lib, dev = _api._resolve()
     mdl = {"pinhole": _lib.PINHOLE, "fisheye": _lib.FISHEYE}[model] if isinstance(model, str) else int(model)
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints, min_points=1)
     E = Engine(mdl, view_ptr, obj, img, dev, lib=lib)
@@ -208,7 +209,7 @@ def solvePnP_batch(objectPoints, imagePoints, cameraMatrix, distCoeffs):
     (homography initialisation + 6-dof refinement on the reprojection error, as
     cv2.solvePnP's SOLVEPNP_ITERATIVE does for planar targets).
     Returns (ok (N,) bool, rvecs (N,3), tvecs (N,3))."""
-    lib, dev = _resolve()
+    lib, dev = _api._resolve()
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
     E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=lib)
     E.set_intr(0, _intr(_lib.PINHOLE, cameraMatrix, distCoeffs))

@@ -247,9 +247,11 @@ class RigEngine:
         poses, board poses from the lowest-numbered camera that sees them.  Writes buffer 0."""
         try:
             self._call("camcal_rig_init", self._rp(), comm.handle(self), self._stream())
-        except _lib.CamcalError as exc:
-            if "status -1" in str(exc):
+        except _lib.CamcalStatus as exc:
+            if exc.code == _lib.E_DISJOINT:
                 raise ValueError("a camera shares no board pose with the rest of the rig") from exc
+            if exc.code == _lib.E_PEER:
+                raise ValueError("the rig initialisation failed on another rank") from exc
             raise
 
     def _comm_pools(self):
@@ -359,7 +361,7 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
     Returns (rms, Ks, Ds, Ts, rvecs, tvecs): Ts[c] = (rvec, tvec) of
     camera-from-rig (camera 0: zeros), rvecs/tvecs the board poses in the rig
     frame (tuples of (3,1) arrays; poses no camera sees keep (0,0,0 | 0,0,1))."""
-    from .api import _resolve
+    from . import api as _api
     mdl = {"pinhole": _lib.PINHOLE, "fisheye": _lib.FISHEYE}[model]
     if cams is None:
         cams, n_poses = _gather_rig(objectPoints, imagePoints)
@@ -374,14 +376,17 @@ def calibrate_rig(objectPoints, imagePoints, imageSize, cameraMatrices, distCoef
         if K.shape != (3, 3) or D.size != nd:
             raise ValueError("cameraMatrix must be 3x3 and distCoeffs hold %d coefficients" % nd)
         intr0[c] = np.concatenate([[K[0, 0], K[1, 1], K[0, 2], K[1, 2]], D])
-    lib, dev = _resolve()
+    lib, dev = _api._resolve()
     R = RigEngine(mdl, cams, n_poses, dev, lib=lib)
     comm = _comm or Comm()
     R.set_params(0, intr0, np.zeros((nC, 6)))
     if _init is None:
         R.init_from_guess(comm)
-        if int(R.status.count_nonzero().item()):
-            raise ValueError("a view is degenerate (collinear / coincident points): its pose initialisation failed")
+        # a collective decision: the ranks that hold no degenerate view must not walk into the loop's all-reduce alone
+        n_bad = int(R.status.count_nonzero().item())
+        if comm.total(n_bad, dev) > 0:
+            raise ValueError("a view is degenerate (collinear / coincident points): its pose initialisation failed"
+                             + ("" if n_bad else " (on another rank)"))
     else:
         R.set_params(0, intr0, _init[0], _init[1])
     NI, G = R.NI, R.G

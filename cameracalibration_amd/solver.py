@@ -71,7 +71,7 @@ class Comm:
         self.enabled = bool(enabled)
         self.group = group
         self.backend = backend or os.environ.get("CAMCAL_COMM") or None
-        self._keep = []            # ctypes callbacks / structs that must outlive the calls
+        self._keep = {}            # id(engine) -> (weakref, callback, struct, pools): must outlive the calls
         self.kind = None           # what the last handle() returned: "rccl" | "torch" | None
 
     def allreduce(self, t: torch.Tensor):
@@ -88,7 +88,8 @@ class Comm:
 
     # -- camcal_comm handles --------------------------------------------------------------
     def _rccl_handle(self, lib, device):
-        key = (id(self.group) if self.group is not None else None,
+        # keyed by the ranks of the group (a group object's id() can be reused after garbage collection)
+        key = (tuple(dist.get_process_group_ranks(self.group)) if self.group is not None else None,
                device.index if device.index is not None else torch.cuda.current_device())
         if key in _RCCL_COMMS:
             return _RCCL_COMMS[key][1]
@@ -138,7 +139,12 @@ class Comm:
                 return -5
         fn = _lib.ALLREDUCE_FN(cb)
         st = _lib.CommStruct(fn, None)
-        self._keep.append((fn, st, pools))
+        # one handle per engine, kept only while the engine lives (a long-lived Comm used for many
+        # solves must not pin every engine's device pool)
+        import weakref
+        key = id(E)
+        self._keep = {k: v for k, v in self._keep.items() if v[0]() is not None}
+        self._keep[key] = (weakref.ref(E), fn, st)
         return C.pointer(st)
 
     def handle(self, E):

@@ -47,6 +47,8 @@ extern "C" {
 #define CAMCAL_E_TOOBIG  (-3)
 #define CAMCAL_E_NUMERIC (-4)   /* a solve met a singular system or a non-finite cost (degenerate views) */
 #define CAMCAL_E_COMM    (-5)   /* RCCL missing or a collective failed */
+#define CAMCAL_E_DISJOINT (-6)  /* camcal_rig_init: a camera shares no board pose with the rest of the rig */
+#define CAMCAL_E_PEER    (-7)   /* multi-rank call: another rank failed before the collective; every rank returns this */
 
 /* Packed observations of the views owned by this process (device pointers). */
 typedef struct camcal_tiles {
@@ -247,6 +249,11 @@ typedef struct camcal_comm {
 int camcal_rccl_unique_id(void* id128_host);
 int camcal_comm_rccl_create(const void* id128_host, int rank, int world_size, camcal_comm** comm_out);
 int camcal_comm_destroy(camcal_comm* comm);
+/* Ranks the communicator sums over: ncclCommCount for a communicator made by
+ * camcal_comm_rccl_create, 1 for comm == NULL, CAMCAL_E_BADARG for a caller-provided callback
+ * communicator (the library cannot know).  For benchmarks and logs that want to state how many
+ * ranks a collective really spanned. */
+int camcal_comm_size(const camcal_comm* comm);
 /* comm->allreduce_sum(...) for hosts without function-pointer calls (ctypes); comm == NULL is
  * the identity (one rank) */
 int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void* stream);
@@ -386,7 +393,10 @@ int camcal_rig_backsub(const camcal_rig* rig, int b, double lam, int out, void* 
  * and refinement (the single-camera kernels), camera-from-rig transforms from the chordal
  * mean of T_pc o T_pk^-1 over shared poses (spanning tree from camera 0 by shared-pose
  * count; the pair sums are summed over the ranks), board poses from the lowest-numbered
- * camera that sees them.  CAMCAL_E_BADARG if a camera shares no pose with the rest. */
+ * camera that sees them.  CAMCAL_E_DISJOINT if a camera shares no pose with the rest.  With a
+ * communicator the failure of any rank's per-camera stage is summed with the pair sums, so
+ * every rank returns an error (the failing rank its own code, the others CAMCAL_E_PEER) and
+ * none is left waiting in a collective. */
 int camcal_rig_init(const camcal_rig* rig, const camcal_comm* comm, void* stream);
 
 /* CvLevMarq::updateAlt over the rig (the control flow of camcal_pinhole_lm) from buffer 0;

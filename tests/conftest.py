@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def use_emulator(lib):
+    """Route every call of the package to the given library (the CPU lane emulator) on the CPU by replacing
+    api._resolve from the outside -- the product itself has no such route.  Returns the undo function."""
+    import torch
+    from cameracalibration_amd import api
+    orig = api._resolve
+    api._resolve = lambda: (lib, torch.device("cpu"))
+    return lambda: setattr(api, "_resolve", orig)
+
+
 @pytest.fixture(scope="session")
 def _emu_lib():
     if not os.path.exists(EMU_PATH):
@@ -26,13 +36,11 @@ def _emu_lib():
 @pytest.fixture()
 def emu(_emu_lib):
     """CPU lane emulator of libcamcal.so (test infrastructure, see tests/hostemu).  While a test
-    holds this fixture every call of the package runs on it (api._set_test_backend, the package's
-    one test hook); explicit Engine(..., lib=emu) constructions work as before."""
-    import torch
-    from cameracalibration_amd import api
-    api._set_test_backend(_emu_lib, torch.device("cpu"))
+    holds this fixture every call of the package runs on it (use_emulator above); explicit
+    Engine(..., lib=emu) constructions work as before."""
+    undo = use_emulator(_emu_lib)
     yield _emu_lib
-    api._set_test_backend(None, None)
+    undo()
 
 
 @pytest.fixture(scope="session")

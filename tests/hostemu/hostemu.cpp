@@ -444,7 +444,13 @@ int camcal_pose_predict(int model, const camcal_tiles* t, const double* Y, const
 }
 int camcal_normal_eq_fused_static(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam,
                                   double* glob, double* schur_out, void* s) {
-  if (t->n_tiles > 16384) return CAMCAL_E_TOOBIG;
+  // the same checks, in the same order, as the HIP build (the emulator walks one view per lane, but the
+  // limit counts the partial records of the mapping the HIP build would choose: camcal_static_partials)
+  if (!t || t->n_tiles <= 0 || t->n_slots != (int64_t)t->n_tiles * LANES || !t->tile_off || !t->tile_nmax || !t->lane_n ||
+      (t->lanes_per_view != 0 && t->lanes_per_view != 1 && t->lanes_per_view != 16 && t->lanes_per_view != 64))
+    return CAMCAL_E_BADARG;
+  if (camcal_glob_len(model) < 0) return CAMCAL_E_BADMODEL;
+  if (static_partials(t->n_tiles, t->planar, t->lanes_per_view) > STATIC_MAX_PARTIALS) return CAMCAL_E_TOOBIG;
   return camcal_normal_eq_fused(model, t, intr, pose, lam, nullptr, nullptr, nullptr, glob, schur_out, nullptr, s);
 }
 int camcal_time_stage(int, int, int, const camcal_tiles*, const double*, const double*, double, double*, double*,
@@ -631,6 +637,7 @@ int camcal_remap_u8(const unsigned char* src, int sw, int sh, int64_t sstride, i
 int camcal_rccl_unique_id(void*) { return CAMCAL_E_COMM; }
 int camcal_comm_rccl_create(const void*, int, int, camcal_comm**) { return CAMCAL_E_COMM; }
 int camcal_comm_destroy(camcal_comm* c) { return c ? CAMCAL_E_BADARG : 0; }
+int camcal_comm_size(const camcal_comm* c) { return c ? CAMCAL_E_BADARG : 1; }
 int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void* stream) {
   if (!comm) return 0;
   if (!comm->allreduce_sum || !buf || n <= 0) return CAMCAL_E_BADARG;

@@ -12,6 +12,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tests.conftest import use_emulator  # noqa: E402
 EMU = os.path.join(ROOT, "tests", "hostemu", "libcamcal_hostemu.so")
 
 
@@ -35,7 +39,7 @@ def _worker(rank, world, port, model, out_dir):
     from cameracalibration_amd.solver import Comm
     emu = _lib.load(EMU)
     from cameracalibration_amd import api
-    api._set_test_backend(emu, torch.device("cpu"))      # the workers run on the CPU lane emulator
+    use_emulator(emu)      # the workers run on the CPU lane emulator
     crit = (3, 1000, 1e-6)
     if model == "fisheye":
         P = synth.config("C3", n_views=90)
@@ -79,3 +83,46 @@ def test_two_rank_solve_equals_single_rank(model, emu, tmp_path):
     rv = np.concatenate([p["rv"] for p in parts])
     tv = np.concatenate([p["tv"] for p in parts])
     assert np.allclose(rv, np.hstack(ref[3]).T, atol=1e-9) and np.allclose(tv, np.hstack(ref[4]).T, atol=1e-7)
+
+
+def _worker_degenerate(rank, world, port, out_dir):
+    """Rank 1 holds a view with collinear corners; both ranks must raise (a rank-local raise
+    leaves the other rank alone in the next collective)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cameracalibration_amd as cc
+    from cameracalibration_amd import _lib, synth, api
+    from cameracalibration_amd.distributed import shard_lists
+    from cameracalibration_amd.solver import Comm
+    use_emulator(_lib.load(EMU))
+    msgs = []
+    for cfg, fn, fl in (("C2", cc.fisheye.calibrate, 8 | 2 | 1), ("C1", cc.calibrateCamera, 1)):
+        P = synth.config(cfg, n_views=16)
+        objs, imgs = P.as_lists()
+        o5 = objs[13].copy(); o5[:, 0, 1] = 0.0
+        i5 = imgs[13].copy(); i5[:, 0, 1] = i5[0, 0, 1]; i5[:, 0, 0] = i5[0, 0, 0] + o5[:, 0, 0]
+        objs[13], imgs[13] = o5, i5                                 # view 13 lives on rank 1
+        o, i, (lo, hi) = shard_lists(objs, imgs, rank, world)
+        assert (lo <= 13 < hi) == (rank == 1)
+        try:
+            fn(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=(3, 30, 1e-6), _comm=Comm())
+            msgs.append("no error")
+        except cc.error as exc:
+            msgs.append(str(exc))
+    # the ranks are still in step: one more collective completes
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    assert t.item() == world
+    with open(os.path.join(out_dir, f"d{rank}.txt"), "w") as f:
+        f.write("\n".join(msgs))
+    dist.destroy_process_group()
+
+
+def test_degenerate_view_on_one_rank_raises_on_every_rank(emu, tmp_path):
+    mp.spawn(_worker_degenerate, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msgs = open(tmp_path / f"d{r}.txt").read().split("\n")
+        assert len(msgs) == 2 and all(m != "no error" for m in msgs), (r, msgs)

@@ -224,6 +224,14 @@ def test_no_cpu_fallback_in_product():
         Engine(0, P.view_ptr, P.obj, P.img, CPU)            # HIP library + cpu tensor
     with pytest.raises(_lib.CamcalError):
         _lib.CamcalLib("/nonexistent/libcamcal.so")
+    # and the package text holds no route to the emulator or the oracle (the tests replace api._resolve from outside)
+    import glob
+    import os
+    pkg = os.path.dirname(os.path.abspath(cc.__file__))
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        text = open(f).read()
+        assert "hostemu" not in text and "import oracle" not in text and "from oracle" not in text, f
+        assert "_set_test_backend" not in text and "_test_backend" not in text, f
 
 
 def test_pose_init_lands_in_basin(emu):
@@ -317,3 +325,27 @@ def cap_hitting_case(fn_kwargs):
 
 def test_cap_hitting_views_match_the_reinitialising_oracle(emu):
     cap_hitting_case(dict())
+
+
+def test_static_entry_rejection_codes_match_the_hip_build(emu):
+    """camcal_normal_eq_fused_static: the limit counts partial records (tiles x lanes per view of the mapping
+    the set gets), and tiles / model are validated first -- the emulator shares the rule with the HIP build
+    (camcal_lane.h: static_partials), so the CPU tier pins the entry point's contract."""
+    import ctypes as C
+    from cameracalibration_amd import _lib
+    libs = [emu, _lib.load()]            # argument checks run before any device work: the HIP build answers without a GPU
+    buf = (C.c_double * 8)()
+    ptr = C.addressof(buf)
+
+    def tiles(nt, lpv, planar=1, slots=None):
+        return _lib.Tiles(ptr, ptr, ptr, ptr, nt, 64 * nt if slots is None else slots, planar, lpv)
+
+    for lib in libs:
+        call = lambda model, t: lib.camcal_normal_eq_fused_static(model, C.byref(t), ptr, ptr, 0.0, ptr, ptr, None)
+        assert call(7, tiles(4, 0)) == -2                # bad model
+        assert call(1, tiles(4, 5)) == -1                # bad lanes_per_view
+        assert call(1, tiles(4, 0, slots=100)) == -1     # n_slots != 64 n_tiles
+        assert call(1, tiles(16385, 1)) == -3            # one lane per view: 16385 partial records
+        assert call(1, tiles(16385, 0, planar=0)) == -3
+        assert call(1, tiles(20000, 64)) == -3           # too many tiles for 64 lanes per view: one lane per view, 20000 records
+    # (a grouped set never exceeds the limit: 32 tiles x 64 lanes = 2048, 448 tiles x 16 lanes = 7168 partial records)

@@ -8,10 +8,8 @@ from tests import points_cases
 
 
 @pytest.fixture()
-def emulated(emu):
-    api._set_test_backend(emu, torch.device("cpu"))
+def emulated(emu):          # the emu fixture already routes the package to the emulator
     yield
-    api._set_test_backend(None, None)
 
 
 @pytest.mark.parametrize("case", points_cases.ALL, ids=[c.__name__ for c in points_cases.ALL])

@@ -19,6 +19,10 @@ from oracle import cvcalib as CC
 from oracle import rig as OR
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import sys
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tests.conftest import use_emulator  # noqa: E402
 EMU = os.path.join(ROOT, "tests", "hostemu", "libcamcal_hostemu.so")
 CPU = torch.device("cpu")
 
@@ -231,7 +235,7 @@ def _worker(rank, world, port, out_dir):
     from cameracalibration_amd.solver import Comm
     emu = _lib.load(EMU)
     from cameracalibration_amd import api
-    api._set_test_backend(emu, torch.device("cpu"))      # the workers run on the CPU lane emulator
+    use_emulator(emu)      # the workers run on the CPU lane emulator
     R = small_rig(24, 3, seed=5)
     objs, imgs = R.as_lists()
     o, i, (lo, hi) = shard_rig_lists(objs, imgs, rank, world)
