@@ -244,6 +244,16 @@ def sharded_solves(dev, lib, rank, world, views_total):
             ms.append(float(t.item()))
         return ms, res
 
+    def all_ok(ok):
+        """Collective: did the section succeed on EVERY rank?  (A rank that failed before or after its
+        collectives must not leave the others to start the next section alone; a rank that dies INSIDE a
+        collective is what the watchdog in main() is for.)"""
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            _all_reduce(t, None, dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    ok = True
     try:
         lo, hi = shard_ranges(np.full(views_total, 88, dtype=np.int64), world)[rank]
         P = synth.config("C5", n_views=hi - lo, device=dev, seed=500 + rank)
@@ -267,6 +277,13 @@ def sharded_solves(dev, lib, rank, world, views_total):
                                              "rank, points already on the device; max over the ranks"}
         del P
         torch.cuda.empty_cache()
+    except Exception as exc:      # reported, never required
+        ok = False
+        out["C5_error"] = "%s: %s" % (type(exc).__name__, exc)
+    if not all_ok(ok):
+        out.setdefault("C5_error", "failed on another rank")
+        return out
+    try:
         R = synth.config("C4", device=dev)            # the same rig on every rank (seeded), then this rank's poses
         cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c]) for c in range(R.n_cams)]
         mine, n_mine, (plo, phi) = shard_rig_cams(cams, R.n_poses, rank, world)
@@ -286,7 +303,10 @@ def sharded_solves(dev, lib, rank, world, views_total):
                                  "note": "board poses split over the ranks, [C|d] and the records summed through the "
                                          "communicator inside camcal_rig_lm; max over the ranks"}
     except Exception as exc:      # reported, never required
-        out["error"] = "%s: %s" % (type(exc).__name__, exc)
+        ok = False
+        out["C4_error"] = "%s: %s" % (type(exc).__name__, exc)
+    if not all_ok(ok):
+        out.setdefault("C4_error", "failed on another rank")
     return out
 
 
@@ -430,9 +450,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solves", action="store_true", help="skip the whole-solve wall-clock extras")
     args = ap.parse_args()
-    if os.environ.get("CAMCAL_BENCH_WATCHDOG"):      # seconds: dump every thread's stack and exit if still running
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["CAMCAL_BENCH_WATCHDOG"]), exit=True)
 
     # ONE JSON line on stdout: everything else a library may print there (RCCL's version banner at
     # communicator creation, ...) goes to stderr; the line itself is written to the saved descriptor
@@ -488,7 +505,31 @@ def main():
         tot = torch.tensor([float(n_obs)], dtype=torch.float64, device=dev)
         if world > 1:
             _all_reduce(tot, None)
+        # what every rank held and how long its kernels took: the line must let a reader check the sharding
+        mine = torch.tensor([float(n_views), float(n_obs), float(region_ms)], dtype=torch.float64, device=dev)
+        if world > 1:
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            if backend == "nccl":
+                dist.all_gather(allr, mine)
+            else:
+                hl = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(hl, mine.cpu())
+                allr = hl
+            per_rank = [dict(rank=r, views=int(t[0].item()), obs=int(t[1].item()), kernel_region_ms=float(t[2].item()))
+                        for r, t in enumerate(allr)]
+        else:
+            per_rank = [dict(rank=0, views=n_views, obs=n_obs, kernel_region_ms=float(region_ms))]
+        # ranks the collective of the step really spanned, as RCCL reports it for the library's communicator
+        if handle is None:
+            nranks = 1
+        elif comm.kind == "rccl":
+            nranks = int(lib.camcal_comm_size(handle))
+        else:
+            nranks = None                 # torch.distributed callback: not an RCCL communicator of the library
+        if comm.kind == "rccl" and nranks != world:
+            raise SystemExit("bench: the RCCL communicator spans %s ranks, --gpus / WORLD_SIZE say %d" % (nranks, world))
         runs[mode] = dict(E=E, n_obs=n_obs, n_views=n_views, el=el, region_ms=region_ms, total_obs=float(tot.item()),
+                          per_rank=per_rank, rccl_nranks=nranks, comm_kind=comm.kind,
                           comm={"rccl": "library RCCL communicator: one ncclAllReduce of 81 doubles per step on the "
                                         "compute stream", "torch": "torch.distributed all_reduce (callback)",
                                 None: None}[comm.kind])
@@ -507,11 +548,8 @@ def main():
             stage_ms[nm] = E.time_stage(st, max(args.steps, 10))
     if world > 1:
         dist.barrier()
-    # whole solves with the set sharded over the ranks: every rank takes part
     progress("stage timings done")
-    sharded = sharded_solves(dev, lib, rank, world, args.views) if (multi and not args.no_solves) else None
-    progress("sharded solves done" if sharded is not None else "no sharded solves")
-
+    out = None
     if rank == 0:
         # the kernel (+ its two tiny reduction launches) over the timed region itself when nothing else
         # runs in it; with an all-reduce in the step, the same launches timed back to back afterwards
@@ -541,7 +579,8 @@ def main():
             "metric": "corner-obs/s for residual+Jacobian+Schur (one normal-equation evaluation)",
             "value": R["total_obs"] * args.steps / el,
             "unit": "corner-obs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm,
+            "n_gpus": world, "rccl_nranks": R["rccl_nranks"], "per_rank": R["per_rank"],
+            "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": headline, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -573,13 +612,47 @@ def main():
                                            "bytes_model is the frozen 20 B/obs + 696 B/view of SURVEY.md 8d "
                                            "(3-D points, blocks stored), which this launch does not move"},
         }
+        # a line whose records did not travel over the library's RCCL communicator between GPUs of their own
+        # (gloo rehearsal with ranks sharing a device, records staged through the host) is a rehearsal of the
+        # control flow, never a measurement: it carries no value
+        rehearsal = multi and (backend != "nccl" or R["comm_kind"] != "rccl")
+        if rehearsal:
+            out["rehearsal"] = True
+            out["rehearsal_value"] = out["value"]
+            out["value"] = None
         if "strong" in runs and headline != "strong":
             S = runs["strong"]
-            out["strong_scaling"] = {"value": S["total_obs"] * args.steps / S["el"], "unit": "corner-obs/s",
+            out["strong_scaling"] = {"value": None if rehearsal else S["total_obs"] * args.steps / S["el"], "unit": "corner-obs/s",
                                      "ms_per_step": S["el"] / args.steps * 1e3, "views_total": args.views,
                                      "views_on_rank0": S["n_views"], "kernel_region_ms_rank0": S["region_ms"],
+                                     "per_rank": S["per_rank"], "rccl_nranks": S["rccl_nranks"],
                                      "note": "BASELINE config 5 as written: the 1M-view set sharded over the ranks "
                                              "(shard_ranges), same step, same collective"}
+    # whole solves with the set sharded over the ranks: every rank takes part.  They are extras of the line:
+    # the headline above is complete before they start, and a deadline makes sure it is written even if a
+    # rank dies inside a collective and leaves the others waiting -- then every rank ends with
+    # status 0 after rank 0 has written the line with the failure noted in it.
+    sharded = None
+    if multi and not args.no_solves:
+        import threading
+        deadline = float(os.environ.get("CAMCAL_BENCH_WATCHDOG", "600"))
+
+        def expired():
+            if rank == 0:
+                out["solve_wall_clock_sharded"] = {"error": "no result within %.0f s: a rank failed inside a "
+                                                            "collective or the solves hung" % deadline}
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            progress("sharded solves: deadline of %.0f s passed, giving up" % deadline)
+            os._exit(0)
+        timer = threading.Timer(deadline + (0.0 if rank == 0 else 10.0), expired)
+        timer.daemon = True
+        timer.start()
+        try:
+            sharded = sharded_solves(dev, lib, rank, world, args.views)
+        finally:
+            timer.cancel()
+    progress("sharded solves done" if sharded is not None else "no sharded solves")
+    if rank == 0:
         if sharded is not None:
             out["solve_wall_clock_sharded"] = sharded
         if world == 1 and not args.no_cpu_baseline:
