@@ -22,7 +22,7 @@ config 4, which the reference does not have.
 server/internal/IntrinsicCalibration/intrinsicCalib.py:102-105,131-134,194-197,223-226).
 """
 from .api import (  # noqa: F401
-    calibrateCamera, error, set_device, CalibrationSession,
+    calibrateCamera, calibrate_many, error, set_device, CalibrationSession,
     TERM_CRITERIA_COUNT, TERM_CRITERIA_MAX_ITER, TERM_CRITERIA_EPS,
     CALIB_USE_INTRINSIC_GUESS, CALIB_FIX_ASPECT_RATIO, CALIB_FIX_PRINCIPAL_POINT,
     CALIB_ZERO_TANGENT_DIST, CALIB_FIX_FOCAL_LENGTH, CALIB_FIX_K1, CALIB_FIX_K2, CALIB_FIX_K3,
@@ -36,4 +36,4 @@ from .points import (  # noqa: F401
 from . import fisheye  # noqa: F401
 from .rig import calibrate_rig  # noqa: F401
 
-__all__ = ["calibrateCamera", "fisheye", "calibrate_rig", "CalibrationSession", "error", "set_device"]
+__all__ = ["calibrateCamera", "fisheye", "calibrate_rig", "calibrate_many", "CalibrationSession", "error", "set_device"]

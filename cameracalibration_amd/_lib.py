@@ -48,6 +48,16 @@ class Rig(C.Structure):
                 ("status", C.c_void_p)]
 
 
+class Problem(C.Structure):
+    """struct camcal_problem (include/camcal.h)."""
+    _fields_ = [("model", C.c_int32), ("flags", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("crit_type", C.c_int32), ("max_iter", C.c_int32), ("eps", C.c_double), ("n_views", C.c_int64),
+                ("view_ptr", C.c_void_p), ("obj", C.c_void_p), ("img", C.c_void_p), ("K", C.c_void_p), ("D", C.c_void_p),
+                ("n_dist", C.c_int32), ("lanes_per_view", C.c_int32), ("rt", C.c_void_p), ("view_status", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("rms", C.c_double),
+                ("iterations", C.c_int32), ("status", C.c_int32)]
+
+
 class CommStruct(C.Structure):
     """struct camcal_comm (include/camcal.h)."""
     _fields_ = [("allreduce_sum", ALLREDUCE_FN), ("ctx", C.c_void_p)]
@@ -83,6 +93,10 @@ _SIGNATURES = {
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "camcal_pinhole_lm": (C.c_int, [_TP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _I, _D, _P, _P,
                                     C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "camcal_workspace_len": (C.c_int64, [_I, C.c_int64, _P]),
+    "camcal_calibrate": (C.c_int, [_I, C.c_int64, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _D, _P, C.c_int64,
+                                   _P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "camcal_calibrate_many": (C.c_int, [C.POINTER(Problem), _I, _P]),
     "camcal_time_stage": (C.c_int, [_I, _I, _I, _TP, _P, _P, _D, _P, _P, _P, _P, _P, _P, _P,
                                     C.POINTER(C.c_float)]),
     "camcal_rig_rec_len": (C.c_int64, [_I, _I]),
@@ -107,7 +121,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
-E_NUMERIC, E_COMM, E_DISJOINT, E_PEER = -4, -5, -6, -7
+E_NUMERIC, E_COMM, E_DISJOINT, E_PEER, E_UNSUPPORTED = -4, -5, -6, -7, -8
 
 
 class CamcalError(RuntimeError):

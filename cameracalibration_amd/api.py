@@ -18,6 +18,9 @@ built extension or calling it without a ROCm device raises.
 """
 from __future__ import annotations
 
+import ctypes as C
+import threading
+
 import numpy as np
 import torch
 
@@ -276,6 +279,174 @@ def _solve_pinhole(E, dev, D, mask, maxc, eps, comm, _info, cameraMatrix, distCo
     return rms, _write_back(cameraMatrix, Kout), _write_back(distCoeffs, Dout), rv, tv
 
 
+# --- the one-call path (camcal_calibrate / camcal_calibrate_many) --------------------------
+# Device workspaces are kept between calls (a call allocates nothing once one of the right size
+# exists): a free list per device, taken and given back under a lock, so concurrent callers
+# each get their own.
+_ws_lock = threading.Lock()
+_ws_free = {}
+
+
+def _take_workspace(dev, nbytes):
+    key = str(dev)
+    with _ws_lock:
+        pool = _ws_free.setdefault(key, [])
+        best = None
+        for i, t in enumerate(pool):
+            if t.numel() >= nbytes + 256 and (best is None or t.numel() < pool[best].numel()):
+                best = i
+        if best is not None:
+            return pool.pop(best)
+    return torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+
+
+def _give_workspace(dev, t):
+    with _ws_lock:
+        pool = _ws_free.setdefault(str(dev), [])
+        pool.append(t)
+        pool.sort(key=lambda x: x.numel())
+        del pool[:-8]                       # keep the eight largest
+
+
+def _problem(lib, dev, model, view_ptr, obj, img, size, K9, D5, n_dist, flags, criteria, keep):
+    """Fill a camcal_problem; ``keep`` collects every array the struct points at."""
+    n_views = len(view_ptr) - 1
+    nbytes = lib.camcal_workspace_len(model, n_views, view_ptr.ctypes.data)
+    if nbytes < 0:
+        lib.check(int(nbytes), "camcal_workspace_len")
+    ws = _take_workspace(dev, nbytes)
+    base = ws.data_ptr()
+    aligned = (base + 255) & ~255
+    rt = np.empty((n_views, 6))
+    status = np.zeros(n_views, dtype=np.int32)
+    obj = np.ascontiguousarray(obj, dtype=np.float32)
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    ctype, maxc, eps = criteria
+    keep.extend([ws, rt, status, obj, img, view_ptr, K9, D5])
+    p = _lib.Problem(model, int(flags), int(size[0]), int(size[1]), int(ctype), int(maxc), float(eps), n_views,
+                     view_ptr.ctypes.data, obj.ctypes.data, img.ctypes.data, K9.ctypes.data, D5.ctypes.data, int(n_dist),
+                     int(Engine.LANES_PER_VIEW), rt.ctypes.data, status.ctypes.data, aligned, ws.numel() - (aligned - base),
+                     0.0, 0, 0)
+    return p, ws, rt, status
+
+
+def _raise_status(rc, status, what):
+    """A camcal_problem's status -> the exception the drop-in raises for it."""
+    if rc == 0:
+        return
+    bad = np.flatnonzero(status != 0)
+    if bad.size:
+        raise error("degenerate view(s) %s: the pose initialisation failed (collinear / coincident points); "
+                    "remove them" % (bad[:16].tolist(),))
+    if rc == _lib.E_NUMERIC:
+        raise error("the solve met a singular system or a non-finite cost (%s)" % what)
+    if rc == _lib.E_UNSUPPORTED:
+        raise error("%s: flag combination or target not supported" % what)
+    raise _lib.CamcalStatus("%s failed with status %d" % (what, rc), rc)
+
+
+def _stream_of(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+
+
+def _one_call(model, view_ptr, obj, img, size, K9, D5, n_dist, flags, criteria):
+    """camcal_calibrate on the resolved library / device -> (rms, K9, D5, rt, iterations)."""
+    lib, dev = _resolve()
+    lib = lib if lib is not None else _lib.load()
+    if dev.type != "cuda" and not lib.is_emulator:
+        raise _lib.CamcalError("the HIP library needs a cuda (ROCm) device; there is no CPU path")
+    keep = []
+    p, ws, rt, status = _problem(lib, dev, model, view_ptr, obj, img, size, K9, D5, n_dist, flags, criteria, keep)
+    rms, its = C.c_double(0.0), C.c_int32(0)
+    try:
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                rc = lib.camcal_calibrate(p.model, p.n_views, p.view_ptr, p.obj, p.img, p.width, p.height, p.K, p.D, p.n_dist,
+                                          p.rt, p.view_status, p.flags, p.crit_type, p.max_iter, p.eps, p.workspace,
+                                          p.workspace_bytes, None, _stream_of(dev), C.byref(rms), C.byref(its))
+        else:
+            rc = lib.camcal_calibrate(p.model, p.n_views, p.view_ptr, p.obj, p.img, p.width, p.height, p.K, p.D, p.n_dist,
+                                      p.rt, p.view_status, p.flags, p.crit_type, p.max_iter, p.eps, p.workspace,
+                                      p.workspace_bytes, None, None, C.byref(rms), C.byref(its))
+    finally:
+        _give_workspace(dev, ws)
+    _raise_status(rc, status, "camcal_calibrate")
+    return float(rms.value), K9, D5, rt, int(its.value)
+
+
+def _pinhole_result(rms, K9, D5, rt, D, cameraMatrix, distCoeffs):
+    Kout = K9.reshape(3, 3)
+    if D.size == 5:
+        Dout = D5.reshape(np.asarray(distCoeffs).shape)
+    else:       # a 4-coefficient guess comes back as cv2's 5-coefficient model (see _solve_pinhole)
+        Dout = D5.reshape((1, 5) if (D.ndim == 2 and D.shape[0] == 1) else (5, 1))
+    rv, tv = _poses_to_tuples(rt)
+    return rms, _write_back(cameraMatrix, Kout), _write_back(distCoeffs, Dout), rv, tv
+
+
+def _fisheye_result(rms, K9, D4, rt, K, D):
+    rv, tv = _poses_to_tuples(rt)
+    return rms, _write_back(K, K9.reshape(3, 3)), _write_back(D, D4.reshape(np.asarray(D).shape)), rv, tv
+
+
+def _k9(intr0):
+    return np.array([intr0[0], 0.0, intr0[2], 0.0, intr0[1], intr0[3], 0.0, 0.0, 1.0])
+
+
+def calibrate_many(calls):
+    """Several independent calibrations in one call -- the reference solves its four cameras one after
+    another (controller/controller_internal_calibration.py:375-399: ``cali_in`` loops over L, ML, MR, R and
+    calls ``cv2.fisheye.calibrate`` / ``cv2.calibrateCamera`` for each).  ``calls``: a sequence of dicts with
+    the arguments of the respective drop-in call, ``dict(model="fisheye" | "pinhole", objectPoints=...,
+    imagePoints=..., imageSize=..., cameraMatrix=..., distCoeffs=..., flags=..., criteria=...)``.  Returns the
+    list of the calls' return tuples ``(retval, K, D, rvecs, tvecs)``, each equal bit for bit to what the
+    call alone returns; K / D are written in place as there.  The solves share the device: every camera's
+    next iteration is enqueued before the host waits for any of them (camcal_calibrate_many)."""
+    lib, dev = _resolve()
+    lib = lib if lib is not None else _lib.load()
+    if dev.type != "cuda" and not lib.is_emulator:
+        raise _lib.CamcalError("the HIP library needs a cuda (ROCm) device; there is no CPU path")
+    keep, items = [], []
+    for c in calls:
+        model = c["model"]
+        flags = int(c.get("flags", 0))
+        if model == "pinhole":
+            crit = c.get("criteria", (TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON))
+            D, intr0, mask, maxc, eps = _prep_pinhole(c["imageSize"], c["cameraMatrix"], c["distCoeffs"], flags, crit)
+            D5 = intr0[4:9].copy()
+            nd, mid = D.size, _lib.PINHOLE
+        elif model == "fisheye":
+            crit = c.get("criteria", (TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON))
+            intr0, mask = _prep_fisheye(c["cameraMatrix"], c["distCoeffs"], flags)
+            D = np.asarray(c["distCoeffs"], dtype=np.float64)
+            D5 = np.asarray(D, dtype=np.float64).ravel().copy()       # the guess as given: the library applies FIX_Ki
+            nd, mid = 4, _lib.FISHEYE
+        else:
+            raise error("model must be 'pinhole' or 'fisheye'")
+        view_ptr, obj, img = _gather_views(c["objectPoints"], c["imagePoints"])
+        K9 = _k9(intr0)
+        p, ws, rt, status = _problem(lib, dev, mid, view_ptr, obj, img, c["imageSize"], K9, D5, nd, flags, crit, keep)
+        items.append((c, model, p, ws, rt, status, K9, D5, D))
+    arr = (_lib.Problem * len(items))(*[it[2] for it in items])
+    try:
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                lib.camcal_calibrate_many(arr, len(items), _stream_of(dev))
+        else:
+            lib.camcal_calibrate_many(arr, len(items), None)
+    finally:
+        for it in items:
+            _give_workspace(dev, it[3])
+    out = []
+    for k, (c, model, _, _, rt, status, K9, D5, D) in enumerate(items):
+        _raise_status(int(arr[k].status), status, "camcal_calibrate_many (problem %d)" % k)
+        if model == "pinhole":
+            out.append(_pinhole_result(float(arr[k].rms), K9, D5, rt, D, c["cameraMatrix"], c["distCoeffs"]))
+        else:
+            out.append(_fisheye_result(float(arr[k].rms), K9, D5, rt, c["cameraMatrix"], c["distCoeffs"]))
+    return out
+
+
 def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs=None,
                     tvecs=None, flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON),
                     *, _comm=None, _info=None):
@@ -296,13 +467,19 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     flags = int(flags)
     D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
+    comm = _comm or _solver.Comm()
+    if _info is None and not comm.enabled:
+        # the plain call: everything behind one library entry point (camcal_calibrate)
+        rms, K9, D5, rt, _ = _one_call(_lib.PINHOLE, view_ptr, obj, img, imageSize, _k9(intr0), intr0[4:9].copy(), D.size,
+                                       flags, criteria)
+        return _pinhole_result(rms, K9, D5, rt, D, cameraMatrix, distCoeffs)
     lib, dev = _resolve()
     E = Engine(_lib.PINHOLE, view_ptr, obj, img, dev, lib=lib)
     E.set_intr(0, intr0)
     # cvFindExtrinsicCameraParams2 per view: homography init + iterative refine
     E.pose_init(0, 0)
     E.pose_refine(0, 0, 20, 1e-10)
-    return _solve_pinhole(E, dev, D, mask, maxc, eps, _comm or _solver.Comm(), _info, cameraMatrix, distCoeffs)
+    return _solve_pinhole(E, dev, D, mask, maxc, eps, comm, _info, cameraMatrix, distCoeffs)
 
 
 def _prep_fisheye(K, D, flags):
@@ -372,13 +549,18 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
     flags = int(flags)
     intr0, mask = _prep_fisheye(K, D, flags)
     view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
+    comm = _comm or _solver.Comm()
+    if _info is None and not comm.enabled:
+        D4 = np.asarray(D, dtype=np.float64).ravel().copy()
+        rms, K9, D4, rt, _ = _one_call(_lib.FISHEYE, view_ptr, obj, img, image_size, _k9(intr0), D4, 4, flags, criteria)
+        return _fisheye_result(rms, K9, D4, rt, K, D)
     lib, dev = _resolve()
     E = Engine(_lib.FISHEYE, view_ptr, obj, img, dev, lib=lib)
     E.set_intr(0, intr0)
     # CalibrateExtrinsics: InitExtrinsics + ComputeExtrinsicRefine per view
     E.pose_init(0, 0)
     E.pose_refine(0, 0, 20, 1e-10)
-    return _solve_fisheye(E, dev, mask, flags, criteria, _comm or _solver.Comm(), _info, K, D)
+    return _solve_fisheye(E, dev, mask, flags, criteria, comm, _info, K, D)
 
 
 class CalibrationSession:

@@ -1,0 +1,397 @@
+// One-call entry points (include/camcal.h: camcal_workspace_len, camcal_calibrate,
+// camcal_calibrate_many): everything cv2.calibrateCamera / cv2.fisheye.calibrate do behind
+// the reference's call sites (camera_calib.py:74-77,153-156; intrinsicCalib.py:102-105,
+// 131-134,194-197,223-226) from host arrays in to host results out -- argument checks, view
+// layout, upload, packing, per-view pose initialisation and refinement, the solver loop
+// (camcal_driver.h), results in the caller's view order -- with every device byte in a
+// workspace the caller owns.  camcal_calibrate_many runs several independent problems (the
+// reference solves its four cameras one after another, controller/
+// controller_internal_calibration.py:375-399) with their steps interleaved on separate
+// streams: the launches of one camera's iteration are enqueued while the others' run.
+//
+// Included by camcal_kernels.hip and by the tests' CPU lane emulator after camcal_driver.h;
+// the includer provides, with internal linkage, besides what camcal_driver.h and
+// camcal_rig_driver.h ask for,
+//   int camcal_upload(void* dst_dev, const void* src_host, size_t bytes, void* stream)
+//   int camcal_download(void* dst_host, const void* src_dev, size_t bytes, void* stream)
+//       (asynchronous, ordered on the stream; the host side must stay valid until the sync)
+//   int camcal_stream_sync(void* stream)
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/camcal.h"
+#include "camcal_driver.h"
+
+namespace {
+namespace camcal_cal {
+
+// cv2 flag bits (calib3d.hpp; the Python drop-in carries the same table)
+constexpr int PH_USE_GUESS = 1, PH_FIX_ASPECT = 2, PH_FIX_PP = 4, PH_ZERO_TANGENT = 8, PH_FIX_FOCAL = 16, PH_FIX_K1 = 32,
+              PH_FIX_K2 = 64, PH_FIX_K3 = 128, PH_RATIONAL = 16384, PH_THIN_PRISM = 32768, PH_TILTED = 262144,
+              PH_FIX_TANGENT = 2097152;
+constexpr int FE_USE_GUESS = 1, FE_RECOMPUTE = 2, FE_CHECK_COND = 4, FE_FIX_SKEW = 8, FE_FIX_K1 = 16, FE_FIX_K2 = 32,
+              FE_FIX_K3 = 64, FE_FIX_K4 = 128, FE_FIX_PP = 512, FE_FIX_FOCAL = 2048;
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t x) { return (x + ALIGN - 1) & ~(ALIGN - 1); }
+
+// Byte offsets of the pieces of a workspace.
+struct Carve {
+  size_t head = 0;                     // [intr0 (16 doubles) | tile_off | view_ptr | slot_view | lane_n | tile_nmax]: one upload
+  size_t tile_off = 0, view_ptr = 0, slot_view = 0, lane_n = 0, tile_nmax = 0, head_bytes = 0;
+  size_t obj = 0, img = 0, pts = 0;
+  size_t intr1 = 0, pose0 = 0, pose1 = 0, V0 = 0, V1 = 0, g0 = 0, g1 = 0, W = 0, rec = 0, glob1 = 0, dK = 0, stats = 0,
+         scratch = 0, status = 0, iters = 0;
+  size_t total = 0;
+};
+
+inline Carve carve(int model, int64_t n_views, int64_t n_obs, int32_t T, int64_t S, int64_t total_floats) {
+  const int ni = camcal_n_intr(model), ng = camcal_glob_len(model), ns = camcal_schur_len(model);
+  Carve c;
+  size_t o = 0;
+  c.head = o;
+  o += 16 * sizeof(double);
+  c.tile_off = o; o += (size_t)T * 8;
+  c.view_ptr = o; o += (size_t)(n_views + 1) * 8;
+  c.slot_view = o; o += (size_t)S * 4;
+  c.lane_n = o; o += (size_t)S * 4;
+  c.tile_nmax = o; o += (size_t)T * 4;
+  c.head_bytes = o;
+  o = up(o);
+  c.obj = o; o = up(o + (size_t)n_obs * 12);
+  c.img = o; o = up(o + (size_t)n_obs * 8);
+  c.pts = o; o = up(o + (size_t)(total_floats > 0 ? total_floats : 1) * 4);
+  auto dbl = [&](size_t n) { const size_t at = o; o = up(o + n * sizeof(double)); return at; };
+  c.intr1 = dbl(16);
+  c.pose0 = dbl(6 * (size_t)S);
+  c.W = dbl((size_t)ni * 6 * S);       // pinhole: the cross blocks; fisheye: the pose response Y
+  c.rec = dbl((size_t)(ng + ns));
+  c.glob1 = dbl((size_t)ng + 2);       // + the two step norms right behind it (one message for a trial point)
+  c.dK = dbl(16);
+  c.stats = dbl(8);
+  if (model == CAMCAL_PINHOLE) {       // CvLevMarq keeps a current and a trial point
+    c.pose1 = dbl(6 * (size_t)S);
+    c.V0 = dbl(21 * (size_t)S);
+    c.V1 = dbl(21 * (size_t)S);
+    c.g0 = dbl(6 * (size_t)S);
+    c.g1 = dbl(6 * (size_t)S);
+  }
+  c.scratch = dbl((size_t)camcal_scratch_len(model, T));
+  c.status = o; o = up(o + (size_t)S * 4);
+  c.iters = o; o = up(o + (size_t)S * 4);
+  c.total = o;
+  return c;
+}
+
+struct Solve {
+  camcal_problem* p = nullptr;
+  const camcal_comm* comm = nullptr;
+  void* stream = nullptr;
+  int rc = 0;
+  bool active = false;
+  // layout
+  int32_t T = 0;
+  int64_t S = 0, total_floats = 0, n_obs = 0;
+  std::vector<char> head;              // host image of the head block
+  Carve c;
+  camcal_tiles tiles{};
+  uint8_t mask[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
+  int ni = 0, crit_type = 3, max_iter = 30;
+  double eps = 0.0;
+  std::unique_ptr<camcal_drv::FisheyeGN> gn;
+  std::unique_ptr<camcal_drv::PinholeLM> lm;
+  // results
+  std::vector<double> h_intr, h_pose, h_tot;
+  std::vector<int32_t> h_status;
+
+  char* ws() const { return (char*)p->workspace; }
+  template <class Tp> Tp* at(size_t off) const { return (Tp*)(ws() + off); }
+
+  // argument checks of the two cv2 calls, as the Python drop-in makes them (api.py: _prep_pinhole / _prep_fisheye)
+  int check(double intr0[16]) {
+    if (!p->view_ptr || !p->obj || !p->img || !p->K || !p->D || !p->rt || !p->workspace || p->n_views <= 0)
+      return CAMCAL_E_BADARG;
+    ni = camcal_n_intr(p->model);
+    if (ni < 0) return CAMCAL_E_BADMODEL;
+    const double* K = p->K;
+    for (int i = 0; i < 16; ++i) intr0[i] = 0.0;
+    intr0[0] = K[0]; intr0[1] = K[4]; intr0[2] = K[2]; intr0[3] = K[5];
+    const int f = p->flags;
+    crit_type = p->crit_type; max_iter = p->max_iter; eps = p->eps;
+    if (p->model == CAMCAL_PINHOLE) {
+      if (f & (PH_FIX_ASPECT | PH_RATIONAL | PH_THIN_PRISM | PH_TILTED)) return CAMCAL_E_UNSUPPORTED;
+      if (!(f & PH_USE_GUESS)) return CAMCAL_E_UNSUPPORTED;
+      if (p->n_dist != 4 && p->n_dist != 5) return CAMCAL_E_BADARG;
+      if (p->width <= 0 || p->height <= 0) return CAMCAL_E_BADARG;
+      if (!(K[0] > 0.0) || !(K[4] > 0.0)) return CAMCAL_E_BADARG;                            // focal lengths
+      if (K[2] < 0 || K[2] >= p->width || K[5] < 0 || K[5] >= p->height) return CAMCAL_E_BADARG;   // principal point
+      if (std::fabs(K[1]) > 1e-5 || std::fabs(K[3]) > 1e-5 || std::fabs(K[6]) > 1e-5 || std::fabs(K[7]) > 1e-5 ||
+          std::fabs(K[8] - 1.0) > 1e-5)
+        return CAMCAL_E_BADARG;
+      for (int i = 0; i < p->n_dist; ++i) intr0[4 + i] = p->D[i];
+      if (f & PH_ZERO_TANGENT) intr0[6] = intr0[7] = 0.0;
+      if (f & PH_FIX_FOCAL) mask[0] = mask[1] = 0;
+      if (f & PH_FIX_PP) mask[2] = mask[3] = 0;
+      if (f & (PH_ZERO_TANGENT | PH_FIX_TANGENT)) mask[6] = mask[7] = 0;
+      if (f & PH_FIX_K1) mask[4] = 0;
+      if (f & PH_FIX_K2) mask[5] = 0;
+      if (f & PH_FIX_K3) mask[8] = 0;
+      if (!(crit_type & 1)) max_iter = 1000;
+      if (!(crit_type & 2)) eps = 2.220446049250313e-16;
+    } else {
+      if (f & FE_CHECK_COND) return CAMCAL_E_UNSUPPORTED;
+      if (!(f & FE_USE_GUESS) || !(f & FE_FIX_SKEW)) return CAMCAL_E_UNSUPPORTED;
+      if (p->n_dist != 4) return CAMCAL_E_BADARG;
+      if (K[1] != 0.0) return CAMCAL_E_UNSUPPORTED;
+      if (crit_type < 1 || crit_type > 3) return CAMCAL_E_BADARG;
+      for (int i = 0; i < 4; ++i) intr0[4 + i] = p->D[i];
+      if (f & FE_FIX_FOCAL) mask[0] = mask[1] = 0;
+      if (f & FE_FIX_PP) mask[2] = mask[3] = 0;
+      const int fk[4] = {FE_FIX_K1, FE_FIX_K2, FE_FIX_K3, FE_FIX_K4};
+      for (int j = 0; j < 4; ++j)
+        if (f & fk[j]) { mask[4 + j] = 0; intr0[4 + j] = 0.0; }
+    }
+    return 0;
+  }
+
+  // everything up to the first step of the loop, enqueued on the stream
+  int setup() {
+    double intr0[16];
+    CAMCAL_DRV_TRY(check(intr0));
+    const int64_t N = p->n_views;
+    if (p->view_ptr[0] != 0) return CAMCAL_E_BADARG;
+    std::vector<int32_t> n_per_view((size_t)N);
+    for (int64_t v = 0; v < N; ++v) {
+      const int64_t n = p->view_ptr[v + 1] - p->view_ptr[v];
+      if (n < 4 || n > 2147483647) return CAMCAL_E_BADARG;       // cv2: every view needs at least 4 points
+      n_per_view[(size_t)v] = (int32_t)n;
+    }
+    n_obs = p->view_ptr[N];
+    for (int64_t i = 0; i < n_obs; ++i)
+      if (p->obj[i * 3 + 2] != 0.f) return CAMCAL_E_UNSUPPORTED;  // planar targets only (the reference's boards)
+    CAMCAL_DRV_TRY(camcal_layout(N, n_per_view.data(), &T, &S, &total_floats, nullptr, nullptr, nullptr, nullptr));
+    c = carve(p->model, N, n_obs, T, S, total_floats);
+    if ((int64_t)c.total > p->workspace_bytes) return CAMCAL_E_TOOBIG;
+    if (((uintptr_t)p->workspace & (ALIGN - 1)) != 0) return CAMCAL_E_BADARG;
+    head.assign(c.head_bytes, 0);
+    std::memcpy(head.data() + c.head, intr0, sizeof(intr0));
+    CAMCAL_DRV_TRY(camcal_layout(N, n_per_view.data(), &T, &S, &total_floats, (int32_t*)(head.data() + c.slot_view),
+                                 (int32_t*)(head.data() + c.lane_n), (int32_t*)(head.data() + c.tile_nmax),
+                                 (int64_t*)(head.data() + c.tile_off)));
+    std::memcpy(head.data() + c.view_ptr, p->view_ptr, (size_t)(N + 1) * 8);
+    CAMCAL_DRV_TRY(camcal_upload(ws() + c.head, head.data(), c.head_bytes, stream));
+    CAMCAL_DRV_TRY(camcal_upload(ws() + c.obj, p->obj, (size_t)n_obs * 12, stream));
+    CAMCAL_DRV_TRY(camcal_upload(ws() + c.img, p->img, (size_t)n_obs * 8, stream));
+    tiles.pts = at<float>(c.pts);
+    tiles.tile_off = at<int64_t>(c.tile_off);
+    tiles.tile_nmax = at<int32_t>(c.tile_nmax);
+    tiles.lane_n = at<int32_t>(c.lane_n);
+    tiles.n_tiles = T;
+    tiles.n_slots = S;
+    tiles.planar = 1;
+    tiles.lanes_per_view = p->lanes_per_view;
+    CAMCAL_DRV_TRY(camcal_pack_tiles(at<float>(c.obj), at<float>(c.img), at<int64_t>(c.view_ptr), at<int32_t>(c.slot_view),
+                                     &tiles, at<float>(c.pts), stream));
+    double* intr = at<double>(c.head);
+    double* pose = at<double>(c.pose0);
+    // cvFindExtrinsicCameraParams2 / CalibrateExtrinsics per view: homography start + refinement
+    CAMCAL_DRV_TRY(camcal_pose_init(p->model, &tiles, intr, pose, at<int32_t>(c.status), stream));
+    CAMCAL_DRV_TRY(camcal_pose_refine(p->model, &tiles, intr, pose, 20, 1e-10, at<int32_t>(c.iters), stream));
+    if (p->model == CAMCAL_FISHEYE) {
+      gn.reset(new camcal_drv::FisheyeGN());
+      gn->tiles = &tiles; gn->intr = intr; gn->pose = pose; gn->mask_host = mask; gn->crit_type = crit_type;
+      gn->max_count = max_iter; gn->eps = eps; gn->recompute_extrinsic = (p->flags & FE_RECOMPUTE) ? 1 : 0;
+      gn->rec = at<double>(c.rec); gn->dK = at<double>(c.dK); gn->stats = at<double>(c.stats);
+      gn->iters = at<int32_t>(c.iters); gn->Y = at<double>(c.W); gn->scratch = at<double>(c.scratch);
+      gn->comm = comm; gn->stream = stream;
+      if (!gn->args_ok()) return CAMCAL_E_BADARG;
+    } else {
+      lm.reset(new camcal_drv::PinholeLM());
+      lm->tiles = &tiles;
+      lm->intr2[0] = intr; lm->intr2[1] = at<double>(c.intr1);
+      lm->pose2[0] = pose; lm->pose2[1] = at<double>(c.pose1);
+      lm->V2[0] = at<double>(c.V0); lm->V2[1] = at<double>(c.V1);
+      lm->g2[0] = at<double>(c.g0); lm->g2[1] = at<double>(c.g1);
+      lm->W = at<double>(c.W); lm->rec = at<double>(c.rec); lm->glob_trial = at<double>(c.glob1);
+      lm->norms = at<double>(c.glob1) + camcal_glob_len(CAMCAL_PINHOLE);
+      lm->dK = at<double>(c.dK); lm->stats = at<double>(c.stats); lm->scratch = at<double>(c.scratch);
+      lm->mask_host = mask; lm->max_iter = max_iter; lm->eps = eps; lm->comm = comm; lm->stream = stream;
+      if (!lm->args_ok()) return CAMCAL_E_BADARG;
+    }
+    active = true;
+    return 0;
+  }
+
+  bool done() const { return gn ? gn->done() : lm ? lm->done() : true; }
+  int launch() { return gn ? gn->launch() : lm->launch(); }
+  int finish() { return gn ? gn->finish() : lm->finish(); }
+
+  // results: enqueue the copies ...
+  int collect_begin() {
+    const int cur = lm ? lm->cur : 0;
+    h_intr.assign(16, 0.0);
+    h_pose.assign((size_t)6 * S, 0.0);
+    h_status.assign((size_t)S, 0);
+    const double* intr = cur ? at<double>(c.intr1) : at<double>(c.head);
+    const double* pose = cur ? at<double>(c.pose1) : at<double>(c.pose0);
+    CAMCAL_DRV_TRY(camcal_download(h_intr.data(), intr, 16 * sizeof(double), stream));
+    CAMCAL_DRV_TRY(camcal_download(h_pose.data(), pose, (size_t)6 * S * sizeof(double), stream));
+    CAMCAL_DRV_TRY(camcal_download(h_status.data(), at<int32_t>(c.status), (size_t)S * sizeof(int32_t), stream));
+    return 0;
+  }
+  // ... and, after the stream has drained, hand them out in the caller's order
+  int collect_end(int loop_rc) {
+    const int32_t* slot_view = (const int32_t*)(head.data() + c.slot_view);
+    int64_t n_bad = 0;
+    for (int64_t s = 0; s < S; ++s) {
+      const int32_t v = slot_view[s];
+      if (v < 0) continue;
+      for (int k = 0; k < 6; ++k) p->rt[(size_t)v * 6 + k] = h_pose[(size_t)k * S + s];
+      if (p->view_status) p->view_status[v] = h_status[(size_t)s];
+      n_bad += h_status[(size_t)s] != 0;
+    }
+    // totals over the ranks (multi-rank call): observations for the rms, degenerate views for a collective verdict
+    double tot[2] = {(double)n_obs, (double)n_bad};
+    if (comm) {
+      double* d = at<double>(c.stats);
+      CAMCAL_DRV_TRY(camcal_upload(d, tot, sizeof(tot), stream));
+      CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, d, 2, stream));
+      CAMCAL_DRV_TRY(camcal_download(tot, d, sizeof(tot), stream));
+      CAMCAL_DRV_TRY(camcal_stream_sync(stream));
+    }
+    if (tot[1] != 0.0) return n_bad ? CAMCAL_E_NUMERIC : CAMCAL_E_PEER;
+    if (loop_rc) return loop_rc;
+    const double cost = gn ? gn->cost : lm->err;
+    p->rms = std::sqrt(cost / tot[0]);
+    p->iterations = gn ? gn->it : lm->iters;
+    double* K = p->K;
+    K[0] = h_intr[0]; K[1] = 0.0; K[2] = h_intr[2];
+    K[3] = 0.0; K[4] = h_intr[1]; K[5] = h_intr[3];
+    K[6] = 0.0; K[7] = 0.0; K[8] = 1.0;
+    const int nd = p->model == CAMCAL_PINHOLE ? 5 : 4;
+    for (int i = 0; i < nd; ++i) p->D[i] = h_intr[4 + i];
+    return 0;
+  }
+};
+
+inline void fail(camcal_problem* p, int rc) {
+  p->status = rc;
+  p->rms = std::nan("");
+  p->iterations = 0;
+}
+
+// the loops of `n` prepared solves, interleaved: every active solve enqueues its next step, then every one
+// waits for its own read-back; finished or failed ones drop out
+inline void run_interleaved(std::vector<std::unique_ptr<Solve>>& sv) {
+  for (;;) {
+    bool any = false;
+    for (auto& s : sv)
+      if (s->active && !s->done()) {
+        const int rc = s->launch();
+        if (rc) { s->rc = rc; s->active = false; } else any = true;
+      }
+    if (!any) break;
+    for (auto& s : sv)
+      if (s->active && !s->done()) {       // (a solve that was launched above is never done before its finish)
+        const int rc = s->finish();
+        if (rc) { s->rc = rc; s->active = false; }
+      }
+  }
+}
+
+}  // namespace camcal_cal
+}  // namespace
+
+extern "C" {
+
+int64_t camcal_workspace_len(int model, int64_t n_views, const int64_t* view_ptr_host) {
+  if (camcal_n_intr(model) < 0) return CAMCAL_E_BADMODEL;
+  if (n_views <= 0 || !view_ptr_host) return CAMCAL_E_BADARG;
+  std::vector<int32_t> n((size_t)n_views);
+  for (int64_t v = 0; v < n_views; ++v) {
+    const int64_t k = view_ptr_host[v + 1] - view_ptr_host[v];
+    if (k < 0 || k > 2147483647) return CAMCAL_E_BADARG;
+    n[(size_t)v] = (int32_t)k;
+  }
+  int32_t T = 0;
+  int64_t S = 0, total = 0;
+  const int rc = camcal_layout(n_views, n.data(), &T, &S, &total, nullptr, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  return (int64_t)camcal_cal::carve(model, n_views, view_ptr_host[n_views], T, S, total).total;
+}
+
+int camcal_calibrate_many(camcal_problem* problems, int n, void* stream) {
+  if (!problems || n <= 0) return CAMCAL_E_BADARG;
+  using camcal_cal::Solve;
+  std::vector<std::unique_ptr<Solve>> sv;
+  // independent problems: one stream each (at most CAMCAL_RIG_MAX_CAMS distinct ones, shared round robin beyond)
+  void* side[CAMCAL_RIG_MAX_CAMS];
+  const int n_streams = n < CAMCAL_RIG_MAX_CAMS ? n : CAMCAL_RIG_MAX_CAMS;
+  CAMCAL_DRV_TRY(camcal_fork_streams(stream, n_streams, side));
+  for (int i = 0; i < n; ++i) {
+    std::unique_ptr<Solve> s(new Solve());
+    s->p = &problems[i];
+    s->stream = side[i % n_streams];
+    problems[i].status = 0;
+    s->rc = s->setup();
+    sv.push_back(std::move(s));
+  }
+  camcal_cal::run_interleaved(sv);
+  for (auto& s : sv)
+    if (s->gn || s->lm) {                        // got as far as the device: read back what there is
+      const int rc = s->collect_begin();
+      if (rc && !s->rc) s->rc = rc;
+    }
+  int first = camcal_join_streams(stream, n_streams, side);
+  const int rcs = camcal_stream_sync(stream);
+  if (!first) first = rcs;
+  for (auto& s : sv) {
+    int rc = s->rc;
+    if ((s->gn || s->lm) && !rcs) rc = s->collect_end(s->rc);
+    if (rc) camcal_cal::fail(s->p, rc);
+    if (rc && !first) first = rc;
+  }
+  return first;
+}
+
+int camcal_calibrate(int model, int64_t n_views, const int64_t* view_ptr_host, const float* obj_host,
+                     const float* img_host, int width, int height, double* K_host, double* D_host, int n_dist,
+                     double* rt_host, int32_t* view_status_host, int flags, int crit_type, int max_iter, double eps,
+                     void* workspace, int64_t workspace_bytes, const camcal_comm* comm, void* stream,
+                     double* rms_out_host, int32_t* iterations_out_host) {
+  if (!rms_out_host || !iterations_out_host) return CAMCAL_E_BADARG;
+  camcal_problem p;
+  std::memset(&p, 0, sizeof(p));
+  p.model = model; p.flags = flags; p.width = width; p.height = height; p.crit_type = crit_type; p.max_iter = max_iter;
+  p.eps = eps; p.n_views = n_views; p.view_ptr = view_ptr_host; p.obj = obj_host; p.img = img_host; p.K = K_host;
+  p.D = D_host; p.n_dist = n_dist; p.rt = rt_host; p.view_status = view_status_host; p.workspace = workspace;
+  p.workspace_bytes = workspace_bytes;
+  camcal_cal::Solve s;
+  s.p = &p;
+  s.comm = comm;
+  s.stream = stream;
+  int rc = s.setup();
+  if (rc == 0) {
+    while (!s.done()) {
+      rc = s.launch();
+      if (rc == 0) rc = s.finish();
+      if (rc) break;
+    }
+  }
+  if (comm && !(s.gn || s.lm)) return rc ? rc : CAMCAL_E_BADARG;   // rejected before any device work: every rank rejects alike
+  if (s.gn || s.lm) {
+    int rc2 = s.collect_begin();
+    if (!rc2) rc2 = camcal_stream_sync(stream);
+    if (!rc2) rc = s.collect_end(rc);
+    else if (!rc) rc = rc2;
+  }
+  *rms_out_host = p.rms;
+  *iterations_out_host = p.iterations;
+  return rc;
+}
+
+}  // extern "C"

@@ -6,6 +6,14 @@
 // the ranks between the stages (include/camcal.h), on the same stream, without a
 // host round trip of their own.
 //
+// Each loop is a small state machine with two halves per step: launch() enqueues
+// the next piece of work on the solve's stream up to (and including) the copy of
+// the few scalars the host decides on, finish() waits for that copy and takes the
+// decision.  A single solve alternates the two; camcal_calibrate_many
+// (camcal_calibrate.h) launches the step of every camera before it waits for any of
+// them, so that independent solves overlap on the device -- same kernels, same
+// order per solve, hence the same bits as solves made one after another.
+//
 // Included by camcal_kernels.hip and by the tests' CPU lane emulator; the
 // includer provides, with internal linkage,
 //   struct camcal_reader {            // one per running solve (RAII)
@@ -29,23 +37,47 @@
     if (rc_ != 0) return rc_;  \
   } while (0)
 
-extern "C" {
+namespace {          // internal linkage, like the includer's camcal_reader
+namespace camcal_drv {
 
-int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
-                      int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec, double* dK,
-                      double* stats, int32_t* iters, double* Y, double* scratch, const camcal_comm* comm, void* stream,
-                      double* cost_out_host, int32_t* iterations_out_host) {
-  if (!tiles || !intr || !pose || !mask_host || !rec || !dK || !stats || !scratch || !cost_out_host ||
-      !iterations_out_host || crit_type < 1 || crit_type > 3)
-    return CAMCAL_E_BADARG;
-  const int ng = camcal_glob_len(CAMCAL_FISHEYE), ns = camcal_schur_len(CAMCAL_FISHEYE);
+// cv::fisheye::calibrate's loop (camera_calib.py:74-77).
+struct FisheyeGN {
+  // arguments of camcal_fisheye_gn
+  const camcal_tiles* tiles = nullptr;
+  double *intr = nullptr, *pose = nullptr;
+  const uint8_t* mask_host = nullptr;
+  int crit_type = 3, max_count = 100;
+  double eps = 0.0;
+  int recompute_extrinsic = 1;
+  double *rec = nullptr, *dK = nullptr, *stats = nullptr;
+  int32_t* iters = nullptr;
+  double *Y = nullptr, *scratch = nullptr;
+  const camcal_comm* comm = nullptr;
+  void* stream = nullptr;
+  // state
   camcal_reader rd;
-  double change = 1.0;
+  double change = 1.0, cost = 0.0;
   int it = 0;
-  for (;;) {
-    if ((crit_type == 1 && it >= max_count) || (crit_type == 2 && change <= eps) ||
-        (crit_type == 3 && (change <= eps || it >= max_count)))
-      break;
+  enum { READY, ITERATION, FINAL_COST, DONE } pending = READY;
+
+  bool args_ok() const {
+    return tiles && intr && pose && mask_host && rec && dK && stats && scratch && crit_type >= 1 && crit_type <= 3;
+  }
+  bool done() const { return pending == DONE; }
+
+  int launch() {
+    if (pending != READY) return CAMCAL_E_BADARG;
+    const int ng = camcal_glob_len(CAMCAL_FISHEYE), ns = camcal_schur_len(CAMCAL_FISHEYE);
+    const bool stop = (crit_type == 1 && it >= max_count) || (crit_type == 2 && change <= eps) ||
+                      (crit_type == 3 && (change <= eps || it >= max_count));
+    if (stop) {
+      CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
+                                        stream));
+      CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rec + ng - 1, 1, stream));
+      CAMCAL_DRV_TRY(rd.begin(rec + ng - 1, 1, 0, stream));
+      pending = FINAL_COST;
+      return 0;
+    }
     const double alpha2 = 1.0 - std::pow(0.6, it + 1.0);
     // with Y (and poses that are re-estimated) the evaluation also leaves every view's first-order
     // response to the intrinsic step, which moves the warm start of the re-estimation below
@@ -56,25 +88,169 @@ int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, con
     CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rec, ng + ns, stream));      // [U|b|cost|C|d] in one message
     CAMCAL_DRV_TRY(camcal_solve_reduced(CAMCAL_FISHEYE, rec, rec + ng, mask_host, 0.0, -alpha2, intr, intr, dK,
                                         stats, stream));
-    double st[5];
     CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
     // cv2 re-estimates the poses before it looks at `change`: the launch does not wait for the host
     if (predict) CAMCAL_DRV_TRY(camcal_pose_predict(CAMCAL_FISHEYE, tiles, Y, dK, -alpha2, iters, 20, pose, stream));
     if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
-    CAMCAL_DRV_TRY(rd.end(st, 5));
-    // a view whose 6x6 block is not positive definite poisons C, d with NaN; a singular reduced
-    // system leaves no step (cv2 would throw from its solve / produce NaN for the caller's checkRange)
-    if (st[4] == 0.0 || !std::isfinite(st[2]) || !std::isfinite(st[3])) return CAMCAL_E_NUMERIC;
-    change = std::sqrt(st[2]) / std::sqrt(st[3]);
-    ++it;
+    pending = ITERATION;
+    return 0;
   }
-  CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
-                                    stream));
-  CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rec + ng - 1, 1, stream));
-  CAMCAL_DRV_TRY(rd.begin(rec + ng - 1, 1, 0, stream));
-  CAMCAL_DRV_TRY(rd.end(cost_out_host, 1));
-  *iterations_out_host = it;
-  return std::isfinite(*cost_out_host) ? 0 : CAMCAL_E_NUMERIC;
+
+  int finish() {
+    if (pending == ITERATION) {
+      double st[5];
+      CAMCAL_DRV_TRY(rd.end(st, 5));
+      // a view whose 6x6 block is not positive definite poisons C, d with NaN; a singular reduced
+      // system leaves no step (cv2 would throw from its solve / produce NaN for the caller's checkRange)
+      if (st[4] == 0.0 || !std::isfinite(st[2]) || !std::isfinite(st[3])) return CAMCAL_E_NUMERIC;
+      change = std::sqrt(st[2]) / std::sqrt(st[3]);
+      ++it;
+      pending = READY;
+      return 0;
+    }
+    if (pending == FINAL_COST) {
+      CAMCAL_DRV_TRY(rd.end(&cost, 1));
+      pending = DONE;
+      return std::isfinite(cost) ? 0 : CAMCAL_E_NUMERIC;
+    }
+    return CAMCAL_E_BADARG;
+  }
+};
+
+// CvLevMarq::updateAlt as cvCalibrateCamera2Internal drives it (camera_calib.py:153-156) on the
+// eliminated system: lambda starts at 1e-3, x10 on a rejected step (only the stored-block Schur
+// kernel is repeated), /10 on an accepted one; stops after max_iter accepted steps or when the
+// relative parameter change < eps.
+struct PinholeLM {
+  const camcal_tiles* tiles = nullptr;
+  double* intr2[2] = {nullptr, nullptr};
+  double* pose2[2] = {nullptr, nullptr};
+  double* V2[2] = {nullptr, nullptr};
+  double* g2[2] = {nullptr, nullptr};
+  double *W = nullptr, *rec = nullptr, *glob_trial = nullptr, *dK = nullptr, *stats = nullptr, *norms = nullptr,
+         *scratch = nullptr;
+  const uint8_t* mask_host = nullptr;
+  int max_iter = 30;
+  double eps = 0.0;
+  const camcal_comm* comm = nullptr;
+  void* stream = nullptr;
+  // state
+  camcal_reader rd;
+  int cur = 0;                         // which physical buffer holds the current point
+  int lam_lg10 = -3, iters = 0;
+  double err = 0.0, prev_err = 0.0;
+  bool fresh = true;
+  enum { START, FIRST_COST, READY, TRIAL, DONE } pending = START;
+
+  bool args_ok() const {
+    if (!tiles || !W || !rec || !glob_trial || !dK || !stats || !norms || !scratch || !mask_host) return false;
+    for (int k = 0; k < 2; ++k)
+      if (!intr2[k] || !pose2[k] || !V2[k] || !g2[k]) return false;
+    return true;
+  }
+  bool done() const { return pending == DONE; }
+
+  int launch() {
+    const int M = CAMCAL_PINHOLE;
+    const int ng = camcal_glob_len(M), ns = camcal_schur_len(M);
+    double* glob = rec;                  // [U|b|cost] of the current point
+    double* schur = rec + ng;            // [C|d]
+    if (pending == START) {
+      max_iter = max_iter < 1 ? 1 : (max_iter > 1000 ? 1000 : max_iter);
+      if (!(eps > 2.220446049250313e-16)) eps = 2.220446049250313e-16;
+      CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[cur], pose2[cur], 1, glob, nullptr, V2[cur], g2[cur], scratch,
+                                        stream));
+      CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob, ng, stream));
+      CAMCAL_DRV_TRY(rd.begin(glob + ng - 1, 1, 0, stream));
+      pending = FIRST_COST;
+      return 0;
+    }
+    if (pending != READY) return CAMCAL_E_BADARG;
+    const int tri = 1 - cur;
+    const double lam = std::pow(10.0, (double)lam_lg10);
+    // evaluation B at the current point for a fresh step, the stored blocks at another lambda otherwise
+    if (fresh) CAMCAL_DRV_TRY(camcal_cross_schur(M, tiles, intr2[cur], pose2[cur], V2[cur], g2[cur], lam, W, schur, scratch, stream));
+    else CAMCAL_DRV_TRY(camcal_schur(M, tiles, V2[cur], W, g2[cur], lam, schur, scratch, stream));
+    CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, schur, ns, stream));
+    CAMCAL_DRV_TRY(camcal_solve_reduced(M, glob, schur, mask_host, lam, -1.0, intr2[cur], intr2[tri], dK, stats, stream));
+    CAMCAL_DRV_TRY(camcal_backsub(M, tiles, V2[cur], W, g2[cur], lam, dK, pose2[cur], pose2[tri], norms, scratch, stream));
+    CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[tri], pose2[tri], 1, glob_trial, nullptr, V2[tri], g2[tri],
+                                      scratch, stream));
+    if (comm) {                                  // the trial point's records: one message when they are adjacent
+      if (norms == glob_trial + ng) CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob_trial, ng + 2, stream));
+      else {
+        CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob_trial, ng, stream));
+        CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, norms, 2, stream));
+      }
+    }
+    // one wait for the three small records
+    CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
+    CAMCAL_DRV_TRY(rd.begin(norms, 2, 5, stream));
+    CAMCAL_DRV_TRY(rd.begin(glob_trial + ng - 1, 1, 7, stream));
+    pending = TRIAL;
+    return 0;
+  }
+
+  int finish() {
+    if (pending == FIRST_COST) {
+      CAMCAL_DRV_TRY(rd.end(&err, 1));
+      prev_err = err;
+      fresh = true;
+      pending = READY;
+      return 0;
+    }
+    if (pending != TRIAL) return CAMCAL_E_BADARG;
+    const int ng = camcal_glob_len(CAMCAL_PINHOLE);
+    double back[8];
+    CAMCAL_DRV_TRY(rd.end(back, 8));
+    err = back[7];
+    if (back[4] == 0.0) return CAMCAL_E_NUMERIC;   // singular reduced system
+    if (err > prev_err) {                          // rejected: the same blocks at ten times the damping
+      ++lam_lg10;
+      if (lam_lg10 <= 16) {
+        fresh = false;
+        pending = READY;
+        return 0;
+      }
+    }
+    lam_lg10 = lam_lg10 - 1 < -16 ? -16 : lam_lg10 - 1;
+    ++iters;
+    const double rel = std::sqrt(back[0] + back[5]) / std::sqrt(back[1] + back[6]);
+    // accept: the trial point becomes the current one
+    CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_trial, ng, stream));
+    cur = 1 - cur;
+    if (iters >= max_iter || rel < eps) {
+      pending = DONE;
+      return std::isfinite(err) ? 0 : CAMCAL_E_NUMERIC;
+    }
+    prev_err = err;
+    fresh = true;
+    pending = READY;
+    return 0;
+  }
+};
+
+}  // namespace camcal_drv
+}  // namespace
+
+extern "C" {
+
+int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
+                      int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec, double* dK,
+                      double* stats, int32_t* iters, double* Y, double* scratch, const camcal_comm* comm, void* stream,
+                      double* cost_out_host, int32_t* iterations_out_host) {
+  camcal_drv::FisheyeGN s;
+  s.tiles = tiles; s.intr = intr; s.pose = pose; s.mask_host = mask_host; s.crit_type = crit_type;
+  s.max_count = max_count; s.eps = eps; s.recompute_extrinsic = recompute_extrinsic; s.rec = rec; s.dK = dK;
+  s.stats = stats; s.iters = iters; s.Y = Y; s.scratch = scratch; s.comm = comm; s.stream = stream;
+  if (!s.args_ok() || !cost_out_host || !iterations_out_host) return CAMCAL_E_BADARG;
+  while (!s.done()) {
+    CAMCAL_DRV_TRY(s.launch());
+    CAMCAL_DRV_TRY(s.finish());
+  }
+  *cost_out_host = s.cost;
+  *iterations_out_host = s.it;
+  return 0;
 }
 
 int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double* const pose2[2],
@@ -82,74 +258,22 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
                       double* dK, double* stats, double* norms, double* scratch, const uint8_t* mask_host,
                       int max_iter, double eps, const camcal_comm* comm, void* stream, double* err_out_host,
                       int32_t* iterations_out_host, int32_t* current_out_host) {
-  if (!tiles || !intr2 || !pose2 || !V2 || !g2 || !W || !rec || !glob_trial || !dK || !stats || !norms || !scratch ||
-      !mask_host || !err_out_host || !iterations_out_host || !current_out_host)
+  if (!intr2 || !pose2 || !V2 || !g2 || !err_out_host || !iterations_out_host || !current_out_host)
     return CAMCAL_E_BADARG;
-  for (int k = 0; k < 2; ++k)
-    if (!intr2[k] || !pose2[k] || !V2[k] || !g2[k]) return CAMCAL_E_BADARG;
-  const int M = CAMCAL_PINHOLE;
-  const int ng = camcal_glob_len(M), ns = camcal_schur_len(M);
-  camcal_reader rd;
-  double* glob = rec;                  // [U|b|cost] of the current point
-  double* schur = rec + ng;            // [C|d]
-  max_iter = max_iter < 1 ? 1 : (max_iter > 1000 ? 1000 : max_iter);
-  if (!(eps > 2.220446049250313e-16)) eps = 2.220446049250313e-16;
-  int cur = 0;                         // which physical buffer holds the current point
-  int lam_lg10 = -3, iters = 0;
-  CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[cur], pose2[cur], 1, glob, nullptr, V2[cur], g2[cur], scratch,
-                                    stream));
-  CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob, ng, stream));
-  double err = 0.0;
-  CAMCAL_DRV_TRY(rd.begin(glob + ng - 1, 1, 0, stream));
-  CAMCAL_DRV_TRY(rd.end(&err, 1));
-  for (;;) {
-    const int tri = 1 - cur;
-    const double prev_err = err;
-    double st[5] = {0, 0, 0, 0, 0}, nr[2] = {0, 0};
-    bool fresh = true;
-    for (;;) {
-      const double lam = std::pow(10.0, (double)lam_lg10);
-      // evaluation B at the current point for a fresh step, the stored blocks at another lambda otherwise
-      if (fresh) CAMCAL_DRV_TRY(camcal_cross_schur(M, tiles, intr2[cur], pose2[cur], V2[cur], g2[cur], lam, W, schur, scratch, stream));
-      else CAMCAL_DRV_TRY(camcal_schur(M, tiles, V2[cur], W, g2[cur], lam, schur, scratch, stream));
-      CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, schur, ns, stream));
-      CAMCAL_DRV_TRY(camcal_solve_reduced(M, glob, schur, mask_host, lam, -1.0, intr2[cur], intr2[tri], dK, stats, stream));
-      CAMCAL_DRV_TRY(camcal_backsub(M, tiles, V2[cur], W, g2[cur], lam, dK, pose2[cur], pose2[tri], norms, scratch, stream));
-      CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[tri], pose2[tri], 1, glob_trial, nullptr, V2[tri], g2[tri],
-                                        scratch, stream));
-      if (comm) {                                  // the trial point's records: one message when they are adjacent
-        if (norms == glob_trial + ng) CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob_trial, ng + 2, stream));
-        else {
-          CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob_trial, ng, stream));
-          CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, norms, 2, stream));
-        }
-      }
-      double back[8];                              // one wait for the three small records
-      CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
-      CAMCAL_DRV_TRY(rd.begin(norms, 2, 5, stream));
-      CAMCAL_DRV_TRY(rd.begin(glob_trial + ng - 1, 1, 7, stream));
-      CAMCAL_DRV_TRY(rd.end(back, 8));
-      for (int i = 0; i < 5; ++i) st[i] = back[i];
-      nr[0] = back[5]; nr[1] = back[6];
-      err = back[7];
-      if (st[4] == 0.0) return CAMCAL_E_NUMERIC;   // singular reduced system
-      if (!(err > prev_err)) break;
-      ++lam_lg10;
-      if (lam_lg10 > 16) break;
-      fresh = false;
-    }
-    lam_lg10 = lam_lg10 - 1 < -16 ? -16 : lam_lg10 - 1;
-    ++iters;
-    const double rel = std::sqrt(st[0] + nr[0]) / std::sqrt(st[1] + nr[1]);
-    // accept: the trial point becomes the current one
-    CAMCAL_DRV_TRY(camcal_copy_doubles(glob, glob_trial, ng, stream));
-    cur = tri;
-    if (iters >= max_iter || rel < eps) break;
+  camcal_drv::PinholeLM s;
+  s.tiles = tiles;
+  for (int k = 0; k < 2; ++k) { s.intr2[k] = intr2[k]; s.pose2[k] = pose2[k]; s.V2[k] = V2[k]; s.g2[k] = g2[k]; }
+  s.W = W; s.rec = rec; s.glob_trial = glob_trial; s.dK = dK; s.stats = stats; s.norms = norms; s.scratch = scratch;
+  s.mask_host = mask_host; s.max_iter = max_iter; s.eps = eps; s.comm = comm; s.stream = stream;
+  if (!s.args_ok()) return CAMCAL_E_BADARG;
+  while (!s.done()) {
+    CAMCAL_DRV_TRY(s.launch());
+    CAMCAL_DRV_TRY(s.finish());
   }
-  *err_out_host = err;
-  *iterations_out_host = iters;
-  *current_out_host = cur;
-  return std::isfinite(err) ? 0 : CAMCAL_E_NUMERIC;
+  *err_out_host = s.err;
+  *iterations_out_host = s.iters;
+  *current_out_host = s.cur;
+  return 0;
 }
 
 }  // extern "C"

@@ -1977,7 +1977,23 @@ int camcal_copy_doubles(double* dst, const double* src, int n, void* stream) {
   HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
+// host <-> workspace copies of camcal_calibrate.h (asynchronous, ordered on the stream)
+int camcal_upload(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+int camcal_download(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+int camcal_stream_sync(void* stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
 }  // namespace
 
 #include "camcal_driver.h"
 #include "camcal_rig_driver.h"
+#include "camcal_calibrate.h"

@@ -48,6 +48,7 @@ extern "C" {
 #define CAMCAL_E_NUMERIC (-4)   /* a solve met a singular system or a non-finite cost (degenerate views) */
 #define CAMCAL_E_COMM    (-5)   /* RCCL missing or a collective failed */
 #define CAMCAL_E_DISJOINT (-6)  /* camcal_rig_init: a camera shares no board pose with the rest of the rig */
+#define CAMCAL_E_UNSUPPORTED (-8) /* camcal_calibrate: a flag combination / target the library does not implement */
 #define CAMCAL_E_PEER    (-7)   /* multi-rank call: another rank failed before the collective; every rank returns this */
 
 /* Packed observations of the views owned by this process (device pointers). */
@@ -300,6 +301,71 @@ int camcal_pinhole_lm(const camcal_tiles* tiles, double* const intr2[2], double*
                       const uint8_t* mask_host, int max_iter, double eps, const camcal_comm* comm,
                       void* stream, double* err_out_host, int32_t* iterations_out_host,
                       int32_t* current_out_host);
+
+/* ---- One call per calibration: host arrays in, host results out, every device byte in a
+ * workspace the caller owns.  These are the two reference calls themselves,
+ *     cv2.calibrateCamera(obj, img, size, K, D, flags=..., criteria=...)    camera_calib.py:153-156,
+ *                                                                            intrinsicCalib.py:194-197,223-226
+ *     cv2.fisheye.calibrate(obj, img, size, K, D, flags=..., criteria=...)  camera_calib.py:74-77,
+ *                                                                            intrinsicCalib.py:102-105,131-134
+ * as a C ABI: argument checks, view layout, upload, packing, per-view pose initialisation and
+ * refinement, the solver loop, results in the caller's view order.  `flags` are cv2's flag
+ * bits of the model's call (calib3d.hpp: CALIB_USE_INTRINSIC_GUESS = 1 ...; fisheye::CALIB_* for
+ * the fisheye model), crit_type / max_iter / eps cv2's TermCriteria (COUNT = 1, EPS = 2).
+ * Supported flag sets as in the Python drop-in; others return
+ * CAMCAL_E_UNSUPPORTED, malformed input CAMCAL_E_BADARG, a degenerate view or a singular
+ * system CAMCAL_E_NUMERIC (view_status then names the views: > 0 = pose initialisation failed).
+ * All pointers of a problem are HOST memory except `workspace` (device, 256-byte aligned,
+ * at least camcal_workspace_len bytes; nothing in it has to be initialised and nothing is
+ * allocated or freed by the call). */
+typedef struct camcal_problem {
+  int32_t model;              /* CAMCAL_PINHOLE / CAMCAL_FISHEYE                                  */
+  int32_t flags;              /* cv2 flag bits of that model's call                               */
+  int32_t width, height;      /* imageSize                                                        */
+  int32_t crit_type, max_iter;/* cv2 TermCriteria                                                 */
+  double  eps;
+  int64_t n_views;
+  const int64_t* view_ptr;    /* [n_views + 1] CSR offsets of the views in obj / img              */
+  const float* obj;           /* [n_obs][3] board points (Z = 0), the reference's float32 lists   */
+  const float* img;           /* [n_obs][2] detected corners                                      */
+  double* K;                  /* [9] row-major 3x3: guess in, result out                          */
+  double* D;                  /* pinhole: 5 doubles (n_dist = 4 or 5 valid on entry, k1 k2 p1 p2 k3
+                                 out); fisheye: 4 (k1..k4): guess in, result out                  */
+  int32_t n_dist;
+  int32_t lanes_per_view;     /* camcal_tiles.lanes_per_view: 0 = chosen by the size of the set   */
+  double* rt;                 /* [n_views][6] out: (rvec, tvec) of every view                     */
+  int32_t* view_status;       /* [n_views] out, may be NULL                                       */
+  void* workspace;            /* DEVICE                                                           */
+  int64_t workspace_bytes;
+  double  rms;                /* out: sqrt(sum of squared residuals / observations)               */
+  int32_t iterations;         /* out                                                              */
+  int32_t status;             /* out (camcal_calibrate_many): 0 or this problem's error           */
+} camcal_problem;
+
+/* Bytes of device workspace a problem of these views needs (HOST view_ptr; no device work). */
+int64_t camcal_workspace_len(int model, int64_t n_views, const int64_t* view_ptr_host);
+
+/* One calibration.  With a communicator every rank calls it with its own shard of the views
+ * and the same guess: the records are summed inside the loop, rms is over all ranks, every
+ * rank receives the same K, D and the poses of its own views; a degenerate view on any rank
+ * fails the call on every rank (CAMCAL_E_NUMERIC where it lives, CAMCAL_E_PEER elsewhere). */
+int camcal_calibrate(int model, int64_t n_views, const int64_t* view_ptr_host, const float* obj_host,
+                     const float* img_host, int width, int height, double* K_host, double* D_host,
+                     int n_dist, double* rt_host, int32_t* view_status_host, int flags, int crit_type,
+                     int max_iter, double eps, void* workspace, int64_t workspace_bytes,
+                     const camcal_comm* comm, void* stream, double* rms_out_host,
+                     int32_t* iterations_out_host);
+
+/* n independent calibrations in one call (the reference solves its four cameras L, ML, MR, R
+ * one after another, controller/controller_internal_calibration.py:375-399): each problem runs
+ * on a stream of its own and the steps of their loops are interleaved -- every camera's next
+ * iteration is enqueued before the host waits for any of them -- so the small launches of a
+ * production-sized solve (25 views x 57 corners) overlap instead of queueing behind each
+ * other's host round trips.  Same kernels in the same order per problem: every result equals
+ * the one camcal_calibrate gives for that problem alone, bit for bit.  Each problem needs its
+ * own workspace.  Returns 0 or the first failing problem's status (problems[i].status holds
+ * each one's; the others are still solved). */
+int camcal_calibrate_many(camcal_problem* problems, int n, void* stream);
 
 /* Timing helper for benchmarks: average duration in milliseconds of `reps`
  * back-to-back launches of one stage (0 = intr_normal, 1 = view_blocks,

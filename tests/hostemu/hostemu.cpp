@@ -726,6 +726,10 @@ int camcal_fork_streams(void* stream, int n, void** side_out) {   // no streams 
   return 0;
 }
 int camcal_join_streams(void*, int, void**) { return 0; }
+int camcal_upload(void* dst, const void* src_host, size_t bytes, void*) { std::memcpy(dst, src_host, bytes); return 0; }
+int camcal_download(void* dst_host, const void* src, size_t bytes, void*) { std::memcpy(dst_host, src, bytes); return 0; }
+int camcal_stream_sync(void*) { return 0; }
 }  // namespace
 #include "../../cameracalibration_amd/csrc/camcal_driver.h"
 #include "../../cameracalibration_amd/csrc/camcal_rig_driver.h"
+#include "../../cameracalibration_amd/csrc/camcal_calibrate.h"

@@ -529,3 +529,51 @@ def case_pose_response_and_predicted_warm_start():
 
 
 ALL.append(case_pose_response_and_predicted_warm_start)
+
+
+def case_one_call_entry_and_calibrate_many():
+    """camcal_calibrate (what the plain drop-in call runs) against the stage-by-stage Engine path (chosen by
+    passing _info), bit for bit; camcal_calibrate_many on the reference's four-camera loop (cali_in:
+    controller_internal_calibration.py:375-399 -- two fisheye and two pinhole cameras, <= 25 ragged views each)
+    against the four calls made one after another, bit for bit, K / D written in place; a degenerate view in one
+    problem fails that problem and names the view."""
+    FEc = FE
+    crit = (3, 1000, 1e-6)
+    calls, single, engine = [], [], []
+    for k, (name, model, nv, seed) in enumerate((("C3", "fisheye", 25, 31), ("C3", "fisheye", 21, 32),
+                                                 ("C1R", "pinhole", 25, 33), ("C1", "pinhole", 20, 34))):
+        P = synth.config(name, n_views=nv, seed=seed)
+        objs, imgs = P.as_lists()
+        fn = cc.fisheye.calibrate if model == "fisheye" else cc.calibrateCamera
+        fl = FEc if model == "fisheye" else cc.CALIB_USE_INTRINSIC_GUESS
+        single.append(fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit))
+        info = {}
+        engine.append(fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit, _info=info))
+        calls.append(dict(model=model, objectPoints=objs, imagePoints=imgs, imageSize=P.image_size,
+                          cameraMatrix=P.K_guess.copy(), distCoeffs=P.D_guess.copy(), flags=fl, criteria=crit))
+    many = cc.calibrate_many(calls)
+    for a, b, e, c in zip(many, single, engine, calls):
+        for x in (b, e):
+            assert a[0] == x[0] and np.array_equal(a[1], x[1]) and np.array_equal(a[2], x[2])
+            assert np.array_equal(np.hstack(a[3]), np.hstack(x[3])) and np.array_equal(np.hstack(a[4]), np.hstack(x[4]))
+        assert a[1] is c["cameraMatrix"] and a[2] is c["distCoeffs"] and a[2].shape == c["distCoeffs"].shape
+    # the 4-coefficient pinhole call through the one-call path: a new 5-element array comes back
+    P = synth.config("C1", n_views=12)
+    objs, imgs = P.as_lists()
+    r = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess[:4].copy(), flags=1, criteria=crit)
+    info = {}
+    e = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess[:4].copy(), flags=1, criteria=crit, _info=info)
+    assert r[2].shape == (5, 1) and np.array_equal(r[2], e[2]) and r[0] == e[0]
+    # a degenerate view in one problem
+    o5 = calls[1]["objectPoints"][5].copy()
+    o5[:, 0, 1] = 0.0
+    i5 = calls[1]["imagePoints"][5].copy()
+    i5[:, 0, 1] = i5[0, 0, 1]
+    i5[:, 0, 0] = i5[0, 0, 0] + o5[:, 0, 0]
+    calls[1]["objectPoints"][5], calls[1]["imagePoints"][5] = o5, i5
+    with pytest.raises(cc.error) as ei:
+        cc.calibrate_many(calls)
+    assert "[5]" in str(ei.value)
+
+
+ALL.append(case_one_call_entry_and_calibrate_many)
