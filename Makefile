@@ -16,7 +16,7 @@ $(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC_HDRS)
 
 hostemu: tests/hostemu/libcamcal_hostemu.so
 tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC_HDRS)
-	g++ -O2 -std=c++17 -fPIC -shared $< -o $@
+	g++ -O2 -std=c++17 -fPIC -shared -pthread $< -o $@
 
 oracle:
 	$(MAKE) -C oracle

@@ -6,8 +6,11 @@
 // (camcal_driver.h), results in the caller's view order -- with every device byte in a
 // workspace the caller owns.  camcal_calibrate_many runs several independent problems (the
 // reference solves its four cameras one after another, controller/
-// controller_internal_calibration.py:375-399) with their steps interleaved on separate
-// streams: the launches of one camera's iteration are enqueued while the others' run.
+// controller_internal_calibration.py:375-399) at once: one host thread and one stream per
+// problem.  A production-sized solve is a chain of ~10 us kernels whose issue rate, not the
+// device, is the limit (measured: the interleaved single-thread form spent 1.9 ms on 300
+// launches that each left the device idle until the next one arrived), so the problems need
+// issuing threads of their own to overlap.
 //
 // Included by camcal_kernels.hip and by the tests' CPU lane emulator after camcal_driver.h;
 // the includer provides, with internal linkage, besides what camcal_driver.h and
@@ -16,11 +19,13 @@
 //   int camcal_download(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 //       (asynchronous, ordered on the stream; the host side must stay valid until the sync)
 //   int camcal_stream_sync(void* stream)
+//   int camcal_get_device(int* dev) / int camcal_set_device(int dev)   (a new host thread starts on device 0)
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/camcal.h"
@@ -284,23 +289,21 @@ inline void fail(camcal_problem* p, int rc) {
   p->iterations = 0;
 }
 
-// the loops of `n` prepared solves, interleaved: every active solve enqueues its next step, then every one
-// waits for its own read-back; finished or failed ones drop out
-inline void run_interleaved(std::vector<std::unique_ptr<Solve>>& sv) {
-  for (;;) {
-    bool any = false;
-    for (auto& s : sv)
-      if (s->active && !s->done()) {
-        const int rc = s->launch();
-        if (rc) { s->rc = rc; s->active = false; } else any = true;
-      }
-    if (!any) break;
-    for (auto& s : sv)
-      if (s->active && !s->done()) {       // (a solve that was launched above is never done before its finish)
-        const int rc = s->finish();
-        if (rc) { s->rc = rc; s->active = false; }
-      }
+// one problem from its host arrays to the point where its results sit in host staging: set-up, loop,
+// read-back, drained stream.  rc: the solve's own status; the return value: whether the read-back worked
+inline int run_to_readback(Solve& s) {
+  s.rc = s.setup();
+  if (s.rc == 0) {
+    while (!s.done()) {
+      int rc = s.launch();
+      if (rc == 0) rc = s.finish();
+      if (rc) { s.rc = rc; break; }
+    }
   }
+  if (!(s.gn || s.lm)) return 0;               // rejected before any device work
+  int rc = s.collect_begin();                  // got as far as the device: read back what there is
+  if (rc == 0) rc = camcal_stream_sync(s.stream);
+  return rc;
 }
 
 }  // namespace camcal_cal
@@ -337,22 +340,27 @@ int camcal_calibrate_many(camcal_problem* problems, int n, void* stream) {
     s->p = &problems[i];
     s->stream = side[i % n_streams];
     problems[i].status = 0;
-    s->rc = s->setup();
     sv.push_back(std::move(s));
   }
-  camcal_cal::run_interleaved(sv);
-  for (auto& s : sv)
-    if (s->gn || s->lm) {                        // got as far as the device: read back what there is
-      const int rc = s->collect_begin();
-      if (rc && !s->rc) s->rc = rc;
-    }
+  int dev = 0;
+  CAMCAL_DRV_TRY(camcal_get_device(&dev));
+  std::vector<int> rb((size_t)n, 0);
+  auto work = [&](int i, bool own_thread) {
+    if (own_thread && camcal_set_device(dev) != 0) { sv[(size_t)i]->rc = CAMCAL_E_BADARG; return; }
+    rb[(size_t)i] = camcal_cal::run_to_readback(*sv[(size_t)i]);
+  };
+  {
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back(work, i, true);
+    work(0, false);
+    for (auto& t : th) t.join();
+  }
   int first = camcal_join_streams(stream, n_streams, side);
-  const int rcs = camcal_stream_sync(stream);
-  if (!first) first = rcs;
-  for (auto& s : sv) {
-    int rc = s->rc;
-    if ((s->gn || s->lm) && !rcs) rc = s->collect_end(s->rc);
-    if (rc) camcal_cal::fail(s->p, rc);
+  for (int i = 0; i < n; ++i) {
+    Solve& s = *sv[(size_t)i];
+    int rc = s.rc;
+    if (s.gn || s.lm) rc = rb[(size_t)i] ? (s.rc ? s.rc : rb[(size_t)i]) : s.collect_end(s.rc);
+    if (rc) camcal_cal::fail(s.p, rc);
     if (rc && !first) first = rc;
   }
   return first;
@@ -374,21 +382,9 @@ int camcal_calibrate(int model, int64_t n_views, const int64_t* view_ptr_host, c
   s.p = &p;
   s.comm = comm;
   s.stream = stream;
-  int rc = s.setup();
-  if (rc == 0) {
-    while (!s.done()) {
-      rc = s.launch();
-      if (rc == 0) rc = s.finish();
-      if (rc) break;
-    }
-  }
-  if (comm && !(s.gn || s.lm)) return rc ? rc : CAMCAL_E_BADARG;   // rejected before any device work: every rank rejects alike
-  if (s.gn || s.lm) {
-    int rc2 = s.collect_begin();
-    if (!rc2) rc2 = camcal_stream_sync(stream);
-    if (!rc2) rc = s.collect_end(rc);
-    else if (!rc) rc = rc2;
-  }
+  const int rb = camcal_cal::run_to_readback(s);
+  int rc = s.rc;
+  if (s.gn || s.lm) rc = rb ? (rc ? rc : rb) : s.collect_end(rc);   // (rejected before any device work: every rank rejects alike)
   *rms_out_host = p.rms;
   *iterations_out_host = p.iterations;
   return rc;

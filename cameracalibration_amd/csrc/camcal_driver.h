@@ -90,8 +90,11 @@ struct FisheyeGN {
                                         stats, stream));
     CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
     // cv2 re-estimates the poses before it looks at `change`: the launch does not wait for the host
-    if (predict) CAMCAL_DRV_TRY(camcal_pose_predict(CAMCAL_FISHEYE, tiles, Y, dK, -alpha2, iters, 20, pose, stream));
-    if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
+    if (predict && iters) CAMCAL_DRV_TRY(camcal_pose_predict_refine(CAMCAL_FISHEYE, tiles, intr, Y, dK, -alpha2, 20, pose, 20, 1e-10, iters, stream));
+    else {
+      if (predict) CAMCAL_DRV_TRY(camcal_pose_predict(CAMCAL_FISHEYE, tiles, Y, dK, -alpha2, iters, 20, pose, stream));
+      if (recompute_extrinsic) CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
+    }
     pending = ITERATION;
     return 0;
   }

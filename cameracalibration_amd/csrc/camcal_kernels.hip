@@ -443,6 +443,23 @@ __global__ void k_expand(const double* __restrict__ red, double* __restrict__ ou
 constexpr int STRAGGLER_LANES = 16;
 constexpr int GROUP = 16;
 
+// k_pose_predict's move applied to a pose just loaded (same arithmetic: lane_pose_predict), for the
+// refinement kernels that start from the predicted pose without a launch of their own for it
+template <int NI>
+__device__ __forceinline__ void predicted_start(const double* __restrict__ Yb, const double* __restrict__ dK, double scale,
+                                                const int32_t* __restrict__ iters, int cap, int64_t S, int64_t slot, int n,
+                                                double p[6]) {
+  if (n <= 0) return;
+  if (iters) {
+    const int last = iters[slot];
+    if (last == 0 || last >= cap) return;
+  }
+  double s[NI];
+#pragma unroll
+  for (int a = 0; a < NI; ++a) s[a] = -scale * dK[a];
+  lane_pose_predict<NI>(Yb, S, slot, s, p);
+}
+
 template <int G>
 __device__ __forceinline__ double group_sum(double x) {
 #pragma unroll
@@ -481,7 +498,9 @@ __device__ __forceinline__ bool group_pose_gn_step(const float* base, int n, con
 template <int MODEL, bool PLANAR>
 __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const double* __restrict__ intr,
                                                         double* __restrict__ pose, int max_iter, double tol,
-                                                        int32_t* __restrict__ iters, int straggler_lanes) {
+                                                        int32_t* __restrict__ iters, int straggler_lanes,
+                                                        const double* __restrict__ Yb, const double* __restrict__ dK,
+                                                        double scale, int cap) {
   constexpr int NI = MT<MODEL>::NI;
   const int tile = blockIdx.x * WPB + (threadIdx.x >> 6);
   if (tile >= t.n_tiles) return;
@@ -491,6 +510,7 @@ __global__ __launch_bounds__(TPB, 2) void k_pose_refine(camcal_tiles t, const do
   double I[NI], p[6];
   load_intr<NI>(intr, I);
   load_pose(pose, S, slot, p);
+  if (Yb) predicted_start<NI>(Yb, dK, scale, iters, cap, S, slot, tv.n, p);   // camcal_pose_predict, in the same launch
   canonical_rvec(p);
   int it = 0;
   double change = 1.0;
@@ -576,7 +596,8 @@ __device__ __forceinline__ bool group_view(const camcal_tiles& t, GroupView& gv)
 template <int MODEL, int G>
 __global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const double* __restrict__ intr,
                                                          double* __restrict__ pose, int max_iter, double tol,
-                                                         int32_t* __restrict__ iters) {
+                                                         int32_t* __restrict__ iters, const double* __restrict__ Yb,
+                                                         const double* __restrict__ dK, double scale, int cap) {
   constexpr int NI = MT<MODEL>::NI;
   GroupView gv;
   if (!group_view<G>(t, gv)) return;
@@ -586,6 +607,7 @@ __global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const d
     double I[NI], q[6];
     load_intr<NI>(intr, I);
     load_pose(pose, S, gv.slot, q);
+    if (Yb) predicted_start<NI>(Yb, dK, scale, iters, cap, S, gv.slot, gv.n, q);   // every lane of the group alike
     canonical_rvec(q);
     double ch = 1.0;
     bool go = ch > tol;
@@ -1334,8 +1356,10 @@ int camcal_pose_init(int model, const camcal_tiles* tiles, const double* intr, d
   return 0;
 }
 
-int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr, double* pose, int max_iter,
-                       double tol, int32_t* iters, void* stream) {
+}  // extern "C"
+namespace {
+int pose_refine_impl(int model, const camcal_tiles* tiles, const double* intr, double* pose, int max_iter,
+                     double tol, int32_t* iters, const double* Y, const double* dK, double scale, int cap, void* stream) {
   if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || max_iter < 0) return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const dim3 g(grid_tiles(tiles)), b(TPB);
@@ -1345,20 +1369,32 @@ int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr,
   if (G > 1) {
     const dim3 gg(grid_groups(tiles, G));
     if (model == CAMCAL_PINHOLE) {
-      if (G == 64) hipLaunchKernelGGL((k_pose_refine_grp<PINHOLE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
-      else hipLaunchKernelGGL((k_pose_refine_grp<PINHOLE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+      if (G == 64) hipLaunchKernelGGL((k_pose_refine_grp<PINHOLE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap);
+      else hipLaunchKernelGGL((k_pose_refine_grp<PINHOLE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap);
     } else {
-      if (G == 64) hipLaunchKernelGGL((k_pose_refine_grp<FISHEYE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
-      else hipLaunchKernelGGL((k_pose_refine_grp<FISHEYE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters);
+      if (G == 64) hipLaunchKernelGGL((k_pose_refine_grp<FISHEYE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap);
+      else hipLaunchKernelGGL((k_pose_refine_grp<FISHEYE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap);
     }
     HIP_TRY(hipGetLastError());
     return 0;
   }
-#define LAUNCH(M, P) hipLaunchKernelGGL((k_pose_refine<M, P>), g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, sl)
+#define LAUNCH(M, P) hipLaunchKernelGGL((k_pose_refine<M, P>), g, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, sl, Y, dK, scale, cap)
   DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
 #undef LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;
+}
+}  // namespace
+extern "C" {
+int camcal_pose_refine(int model, const camcal_tiles* tiles, const double* intr, double* pose, int max_iter,
+                       double tol, int32_t* iters, void* stream) {
+  return pose_refine_impl(model, tiles, intr, pose, max_iter, tol, iters, nullptr, nullptr, 0.0, 0, stream);
+}
+int camcal_pose_predict_refine(int model, const camcal_tiles* tiles, const double* intr, const double* Y,
+                               const double* dK, double scale, int cap, double* pose, int max_iter, double tol,
+                               int32_t* iters, void* stream) {
+  if (!Y || !dK) return CAMCAL_E_BADARG;
+  return pose_refine_impl(model, tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap, stream);
 }
 
 int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
@@ -1990,6 +2026,14 @@ int camcal_download(void* dst_host, const void* src_dev, size_t bytes, void* str
 }
 int camcal_stream_sync(void* stream) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+int camcal_get_device(int* dev) {
+  HIP_TRY(hipGetDevice(dev));
+  return 0;
+}
+int camcal_set_device(int dev) {
+  HIP_TRY(hipSetDevice(dev));
   return 0;
 }
 }  // namespace

@@ -1,8 +1,10 @@
 // Host program that calibrates a synthetic Kannala-Brandt camera through the C ABI
 // alone (include/camcal.h + the HIP runtime for memory): no Python, no torch.
-// It is the sequence cv2.fisheye.calibrate runs at the reference's call site
+// It is cv2.fisheye.calibrate as the reference calls it at
 // server/aruco/camera_calib.py:74-77 (flags FIX_SKEW | RECOMPUTE_EXTRINSIC |
-// USE_INTRINSIC_GUESS, criteria (EPS + COUNT, 1000, 1e-6)).
+// USE_INTRINSIC_GUESS, criteria (EPS + COUNT, 1000, 1e-6)) through the one-call entry
+// point camcal_calibrate: host arrays in, host results out, one caller-owned workspace.
+// (examples/cabi_rig.cpp drives a solve stage by stage instead.)
 //
 //   make examples && examples/cabi_fisheye        (prints the recovered intrinsics, exit 0 on success)
 #include <hip/hip_runtime.h>
@@ -25,13 +27,6 @@ static void rodrigues(const double r[3], double R[9]) {
   const double M[9] = {c + c1 * x * x, c1 * x * y - s * z, c1 * x * z + s * y, c1 * x * y + s * z, c + c1 * y * y,
                        c1 * y * z - s * x, c1 * x * z - s * y, c1 * y * z + s * x, c + c1 * z * z};
   for (int i = 0; i < 9; ++i) R[i] = M[i];
-}
-
-template <typename T> static T* to_device(const std::vector<T>& v) {
-  T* d = nullptr;
-  if (hipMalloc(&d, sizeof(T) * (v.empty() ? 1 : v.size())) != hipSuccess) return nullptr;
-  if (!v.empty() && hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-  return d;
 }
 
 int main() {
@@ -66,65 +61,32 @@ int main() {
     n_per_view[v] = cnt;
     view_ptr[v + 1] = view_ptr[v] + cnt;
   }
-  // layout (host) and device buffers
-  int32_t n_tiles = 0;
-  int64_t n_slots = 0, total = 0;
-  CC_OK(camcal_layout(n_views, n_per_view.data(), &n_tiles, &n_slots, &total, nullptr, nullptr, nullptr, nullptr));
-  std::vector<int32_t> slot_view(n_slots), lane_n(n_slots), tile_nmax(n_tiles);
-  std::vector<int64_t> tile_off(n_tiles);
-  CC_OK(camcal_layout(n_views, n_per_view.data(), &n_tiles, &n_slots, &total, slot_view.data(), lane_n.data(),
-                      tile_nmax.data(), tile_off.data()));
-  float* d_obj = to_device(obj); float* d_img = to_device(img);
-  int64_t* d_vp = to_device(view_ptr); int32_t* d_sv = to_device(slot_view);
-  int32_t* d_ln = to_device(lane_n); int32_t* d_nm = to_device(tile_nmax); int64_t* d_to = to_device(tile_off);
-  float* d_pts = nullptr;
-  HIP_OK(hipMalloc(&d_pts, sizeof(float) * (total > 0 ? total : 1)));
-  camcal_tiles tiles = {d_pts, d_to, d_nm, d_ln, n_tiles, n_slots, 1};
-  CC_OK(camcal_pack_tiles(d_obj, d_img, d_vp, d_sv, &tiles, d_pts, nullptr));
-  const int ng = camcal_glob_len(CAMCAL_FISHEYE), ns = camcal_schur_len(CAMCAL_FISHEYE);
-  double *d_intr, *d_pose, *d_rec, *d_dK, *d_stats, *d_scratch;
-  int32_t *d_status, *d_iters;
-  HIP_OK(hipMalloc(&d_intr, 16 * sizeof(double)));
-  HIP_OK(hipMalloc(&d_pose, 6 * n_slots * sizeof(double)));
-  HIP_OK(hipMalloc(&d_rec, (ng + ns) * sizeof(double)));
-  HIP_OK(hipMalloc(&d_dK, 16 * sizeof(double)));
-  HIP_OK(hipMalloc(&d_stats, 8 * sizeof(double)));
-  HIP_OK(hipMalloc(&d_scratch, camcal_scratch_len(CAMCAL_FISHEYE, n_tiles) * sizeof(double)));
-  HIP_OK(hipMalloc(&d_status, n_slots * sizeof(int32_t)));
-  HIP_OK(hipMalloc(&d_iters, n_slots * sizeof(int32_t)));
-  double intr16[16] = {0};
-  for (int i = 0; i < 8; ++i) intr16[i] = guess[i];
-  HIP_OK(hipMemcpy(d_intr, intr16, sizeof(intr16), hipMemcpyHostToDevice));
-  // cv::fisheye::calibrate: CalibrateExtrinsics, then damped Gauss-Newton with pose re-estimation;
-  // run twice, the second time on the clock (the first pays for code-object loading)
-  double change = 1.0, stats[8], rec[64];
-  int it = 0;
+  // one workspace, one call: cv2.fisheye.calibrate(obj, img, size, K, D, flags = FIX_SKEW | RECOMPUTE_EXTRINSIC |
+  // USE_INTRINSIC_GUESS, criteria = (EPS + COUNT, 1000, 1e-6)) -- camera_calib.py:74-77
+  const int64_t ws_bytes = camcal_workspace_len(CAMCAL_FISHEYE, n_views, view_ptr.data());
+  if (ws_bytes <= 0) { std::fprintf(stderr, "camcal_workspace_len -> %lld\n", (long long)ws_bytes); return 3; }
+  void* ws = nullptr;
+  HIP_OK(hipMalloc(&ws, (size_t)ws_bytes));
+  std::vector<double> rt((size_t)n_views * 6);
+  std::vector<int32_t> view_status(n_views);
+  double K[9], D[4], rms = 0.0;
+  int32_t it = 0;
   double wall_ms = 0.0;
-  for (int pass = 0; pass < 2; ++pass) {
-  HIP_OK(hipMemcpy(d_intr, intr16, sizeof(intr16), hipMemcpyHostToDevice));
-  HIP_OK(hipDeviceSynchronize());
-  const auto t0 = std::chrono::steady_clock::now();
-  CC_OK(camcal_pose_init(CAMCAL_FISHEYE, &tiles, d_intr, d_pose, d_status, nullptr));
-  CC_OK(camcal_pose_refine(CAMCAL_FISHEYE, &tiles, d_intr, d_pose, 20, 1e-10, d_iters, nullptr));
-  const uint8_t mask[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-  change = 1.0;
-  for (it = 0; it < 1000 && change > 1e-6; ++it) {
-    CC_OK(camcal_normal_eq_fused(CAMCAL_FISHEYE, &tiles, d_intr, d_pose, 0.0, nullptr, nullptr, nullptr, d_rec,
-                                 d_rec + ng, d_scratch, nullptr));
-    CC_OK(camcal_solve_reduced(CAMCAL_FISHEYE, d_rec, d_rec + ng, mask, 0.0, -(1.0 - std::pow(0.6, it + 1.0)), d_intr,
-                               d_intr, d_dK, d_stats, nullptr));
-    HIP_OK(hipMemcpy(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost));
-    change = std::sqrt(stats[2]) / std::sqrt(stats[3]);
-    CC_OK(camcal_pose_refine(CAMCAL_FISHEYE, &tiles, d_intr, d_pose, 20, 1e-10, d_iters, nullptr));
+  for (int pass = 0; pass < 2; ++pass) {       // the second pass is on the clock (the first pays for code-object loading)
+    const double K0[9] = {guess[0], 0, guess[2], 0, guess[1], guess[3], 0, 0, 1};
+    for (int i = 0; i < 9; ++i) K[i] = K0[i];
+    for (int i = 0; i < 4; ++i) D[i] = guess[4 + i];
+    HIP_OK(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    CC_OK(camcal_calibrate(CAMCAL_FISHEYE, n_views, view_ptr.data(), obj.data(), img.data(), 2960, 1664, K, D, 4,
+                           rt.data(), view_status.data(), /*flags*/ 8 | 2 | 1, /*criteria*/ 3, 1000, 1e-6, ws, ws_bytes,
+                           /*comm*/ nullptr, /*stream*/ nullptr, &rms, &it));
+    wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
-  CC_OK(camcal_intr_normal(CAMCAL_FISHEYE, &tiles, d_intr, d_pose, 0, d_rec, nullptr, nullptr, nullptr, d_scratch, nullptr));
-  HIP_OK(hipMemcpy(rec, d_rec, ng * sizeof(double), hipMemcpyDeviceToHost));
-  wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  }
-  HIP_OK(hipMemcpy(intr16, d_intr, sizeof(intr16), hipMemcpyDeviceToHost));
-  std::printf("solve wall clock %.3f ms (%d views, points resident)\n", wall_ms, n_views);
-  const double rms = std::sqrt(rec[ng - 1] / (double)view_ptr[n_views]);
-  std::printf("iterations %d  rms %.3e px\n", it, rms);
+  double intr16[16] = {K[0], K[4], K[2], K[5], D[0], D[1], D[2], D[3]};
+  std::printf("solve wall clock %.3f ms (%d views, host arrays in, host results out)\n", wall_ms, n_views);
+  std::printf("iterations %d  rms %.3e px  first view: r = (%.4f %.4f %.4f) t = (%.2f %.2f %.2f)\n", it, rms, rt[0], rt[1],
+              rt[2], rt[3], rt[4], rt[5]);
   double worst = 0.0;
   for (int i = 0; i < 4; ++i) {
     std::printf("  intr[%d] = %.6f (truth %.6f)\n", i, intr16[i], truth[i]);

@@ -212,6 +212,14 @@ int camcal_normal_eq_fused_response(int model, const camcal_tiles* tiles, const 
 int camcal_pose_predict(int model, const camcal_tiles* tiles, const double* Y, const double* dK,
                         double scale, const int32_t* iters, int cap, double* pose, void* stream);
 
+/* camcal_pose_predict followed by camcal_pose_refine in ONE launch (the refinement kernels apply
+ * the move to the pose they have just loaded): same arithmetic, same results bit for bit, one
+ * kernel and one pass over the poses less per iteration of the fisheye loop.  iters: step
+ * counts of the last refinement in (the skip rule of camcal_pose_predict), of this one out. */
+int camcal_pose_predict_refine(int model, const camcal_tiles* tiles, const double* intr, const double* Y,
+                               const double* dK, double scale, int cap, double* pose, int max_iter,
+                               double tol, int32_t* iters, void* stream);
+
 /* The evaluation of camcal_normal_eq_fused (no block stores: V = W = g = NULL) for callers
  * that cannot allocate device memory or carry a workspace: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.

@@ -442,6 +442,12 @@ int camcal_pose_predict(int model, const camcal_tiles* t, const double* Y, const
   }
   return 0;
 }
+int camcal_pose_predict_refine(int model, const camcal_tiles* t, const double* intr, const double* Y, const double* dK,
+                               double scale, int cap, double* pose, int max_iter, double tol, int32_t* iters, void* s) {
+  if (!Y || !dK) return CAMCAL_E_BADARG;
+  const int rc = camcal_pose_predict(model, t, Y, dK, scale, iters, cap, pose, s);
+  return rc ? rc : camcal_pose_refine(model, t, intr, pose, max_iter, tol, iters, s);
+}
 int camcal_normal_eq_fused_static(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam,
                                   double* glob, double* schur_out, void* s) {
   // the same checks, in the same order, as the HIP build (the emulator walks one view per lane, but the
@@ -729,6 +735,8 @@ int camcal_join_streams(void*, int, void**) { return 0; }
 int camcal_upload(void* dst, const void* src_host, size_t bytes, void*) { std::memcpy(dst, src_host, bytes); return 0; }
 int camcal_download(void* dst_host, const void* src, size_t bytes, void*) { std::memcpy(dst_host, src, bytes); return 0; }
 int camcal_stream_sync(void*) { return 0; }
+int camcal_get_device(int* dev) { *dev = 0; return 0; }
+int camcal_set_device(int) { return 0; }
 }  // namespace
 #include "../../cameracalibration_amd/csrc/camcal_driver.h"
 #include "../../cameracalibration_amd/csrc/camcal_rig_driver.h"
