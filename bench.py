@@ -77,7 +77,7 @@ def cpu_baseline(seconds_target=12.0):
     per-view accumulation) on a bounded sample of the same workload."""
     try:
         from oracle import cport
-        nthreads = min(16, os.cpu_count() or 1)
+        nthreads = host_threads()
         n_views = 20000
         P = synth.config("C5", n_views=n_views, device="cpu")
         intr = P.intr_guess()
@@ -92,10 +92,73 @@ def cpu_baseline(seconds_target=12.0):
             if el > seconds_target or reps >= 100000:
                 break
         return {"value": P.n_obs * reps / el, "unit": "corner-obs/s", "cores": nthreads, "kind": "port",
+                "host_cpu_count": os.cpu_count(),
                 "sample": f"{reps} evaluations of {n_views} fisheye views x 88 corners (oracle/normal_eq.c, "
-                          f"OpenMP {nthreads} threads, {el:.1f} s)"}
+                          f"OpenMP {nthreads} threads = the box's CPU share of {os.cpu_count()} host CPUs, {el:.1f} s)"}
     except Exception as exc:  # the baseline is reported, never required
         return {"value": None, "unit": "corner-obs/s", "cores": 0, "kind": "port", "sample": f"failed: {exc}"}
+
+
+def host_threads():
+    """Threads the CPU legs use: the box's CPU share (OMP_NUM_THREADS is set to it there), else every core."""
+    try:
+        return max(1, int(os.environ.get("OMP_NUM_THREADS", "") or (os.cpu_count() or 1)))
+    except ValueError:
+        return os.cpu_count() or 1
+
+
+def cpu_port_solves():
+    """the repo's own Schur-based CPU restatement -- the solver's per-view C++ code looped
+    over the views with OpenMP on all host cores (oracle/libcamcal_cpu.so, built from tests/hostemu) -- timed on
+    every config: C1 / C2 in full, C3 / C5 on a 20 000-view sample of the same generator (the form is linear in
+    the views), C4 on a 200-pose rig.  A stated baseline, never the target."""
+    from cameracalibration_amd import rig, solver
+    out = {"threads": host_threads(), "host_cpu_count": os.cpu_count(),
+           "what": "oracle/libcamcal_cpu.so: the solver's per-view C++ code behind the same C ABI, OpenMP over tiles"}
+    cpu = _lib.load(os.path.join(HERE, "oracle", "libcamcal_cpu.so"))
+    dev = torch.device("cpu")
+
+    def timed(fn, reps=2):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts), r
+
+    for key, name, nv, mid in (("C1_pinhole_20x54", "C1", 20, 0), ("C2_fisheye_500x88", "C2", 500, 1),
+                               ("C3_fisheye_100k_ragged_views", "C3", 20000, 1), ("C5_fisheye_1M_views", "C5", 20000, 1)):
+        P = synth.config(name, n_views=nv)
+
+        def solve():
+            E = Engine(mid, P.view_ptr, P.obj, P.img, dev, lib=cpu)
+            E.set_intr(0, P.intr_guess())
+            E.pose_init(0, 0)
+            E.pose_refine(0, 0, 20, 1e-10)
+            if mid == 1:
+                return solver.gn_fisheye(E, np.ones(8, dtype=bool), (3, 1000, 1e-6))
+            return solver.lm_pinhole(E, np.ones(9, dtype=bool), 1000, 1e-6)
+        ms, (cost, it) = timed(solve)
+        out[key] = {"views": nv, "ms": ms, "iterations": it, "rms_px": float(np.sqrt(cost / P.n_obs)),
+                    "ms_per_1000_views": ms * 1000.0 / nv}
+    R = synth.config("C4", n_views=200)
+    cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c]) for c in range(R.n_cams)]
+    Ks, Ds = R.guess_matrices()
+    from cameracalibration_amd import api
+    orig = api._resolve
+    api._resolve = lambda: (cpu, dev)        # this leg only: the rig front end resolves its library through api._resolve
+    try:
+        def rig_solve():
+            info = {}
+            r = rig.calibrate_rig(None, None, R.image_size, Ks, Ds, criteria=(3, 100, 1e-7), cams=cams, n_poses=R.n_poses,
+                                  _info=info)
+            return r[0], info["iters"]
+        ms, (rms, it) = timed(rig_solve)
+    finally:
+        api._resolve = orig
+    out["C4_rig_4x10000_poses"] = {"poses": 200, "ms": ms, "iterations": it, "rms_px": float(rms),
+                                   "ms_per_1000_poses": ms * 1000.0 / 200}
+    return out
 
 
 def big_solve(name, n_views, dev, lib):
@@ -180,6 +243,29 @@ def solve_times(dev, with_cpu=True):
             out["C2_fisheye_500x88"]["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
             out["C2_fisheye_500x88"]["cpu_oracle"] = ("oracle/cvcalib.py Schur-eliminated Gauss-Newton, numpy, 1 thread (cv2's dense "
                                                       "formulation of the same loop needs a 3008 x 3008 J^T J per iteration)")
+        # the reference's real loop: cali_in solves its four cameras one after another
+        # (controller/controller_internal_calibration.py:375-399; two fisheye + two pinhole, <= 25 ragged views each)
+        calls = []
+        for nm, model, seed in (("C3", "fisheye", 31), ("C3", "fisheye", 32), ("C1R", "pinhole", 33), ("C1R", "pinhole", 34)):
+            Pc = synth.config(nm, n_views=25, seed=seed)
+            oc, ic = Pc.as_lists()
+            calls.append(dict(model=model, objectPoints=oc, imagePoints=ic, imageSize=Pc.image_size, cameraMatrix=Pc.K_guess,
+                              distCoeffs=Pc.D_guess, flags=fe if model == "fisheye" else 1, criteria=crit))
+
+        def fresh():
+            return [dict(c, cameraMatrix=c["cameraMatrix"].copy(), distCoeffs=c["distCoeffs"].copy()) for c in calls]
+
+        def one_by_one():
+            for c in fresh():
+                fn = cc.fisheye.calibrate if c["model"] == "fisheye" else cc.calibrateCamera
+                fn(c["objectPoints"], c["imagePoints"], c["imageSize"], c["cameraMatrix"], c["distCoeffs"], flags=c["flags"],
+                   criteria=c["criteria"])
+        ms_seq, _ = med(one_by_one)
+        ms_many, _ = med(lambda: cc.calibrate_many(fresh()))
+        out["production_4cams"] = {"ms": ms_many, "one_after_another_ms": ms_seq,
+                                   "what": "2 fisheye + 2 pinhole cameras, 25 ragged views (13..63 corners) each: "
+                                           "calibrate_many (camcal_calibrate_many: one host thread and stream per camera) "
+                                           "against the four drop-in calls in sequence; host lists in, results out"}
         R = synth.config("C4", device=dev)
         cams = [dict(pose_idx=R.pose_idx[c], view_ptr=R.view_ptr[c], obj=R.obj[c], img=R.img[c])
                 for c in range(R.n_cams)]
@@ -216,6 +302,11 @@ def solve_times(dev, with_cpu=True):
                                                          "%d-view sample of the same generator (linear in the views)" % nv}
     except Exception as exc:      # reported, never required
         out["error"] = str(exc)
+    if with_cpu:
+        try:
+            out["cpu_port"] = cpu_port_solves()
+        except Exception as exc:
+            out["cpu_port"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return out
 
 

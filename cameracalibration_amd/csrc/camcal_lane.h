@@ -41,6 +41,27 @@ CC_HD void for_each_obs(const LaneTile& tv, F&& f) {
   if (k < tv.nmax && k < tv.n) f(a);
 }
 
+// The same walk with every corner loaded THREE steps ahead of its use (four corners per trip,
+// three in flight).  A corner of the pose refinement is ~800 issue cycles at two wavefronts per
+// SIMD, less than a trip to HBM under load, so a single corner of look-ahead leaves the loop
+// waiting for its points; the extra look-ahead costs 8 more float registers.
+template <bool PLANAR, class F>
+CC_HD void for_each_obs_deep(const LaneTile& tv, F&& f) {
+  const int last = tv.nmax > 0 ? tv.nmax - 1 : 0;
+  auto at = [&](int k) { return load_obs<PLANAR>(tv.base, k < last ? k : last); };
+  Obs q0 = at(0), q1 = at(1), q2 = at(2);
+  for (int k = 0; k < tv.nmax; k += 4) {
+    const Obs q3 = at(k + 3);
+    if (k < tv.n) f(q0);
+    q0 = at(k + 4);
+    if (k + 1 < tv.n) f(q1);
+    q1 = at(k + 5);
+    if (k + 2 < tv.n) f(q2);
+    q2 = at(k + 6);
+    if (k + 3 < tv.n) f(q3);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K1: per-view blocks V, W, g of the normal equations (Rodrigues frame).
 template <int MODEL, bool PLANAR>
@@ -383,7 +404,10 @@ CC_HD bool lane_pose_gn_step(const LaneTile& tv, const double* intr, double pose
   for (int i = 0; i < 21; ++i) V[i] = 0.0;
   CC_UNROLL
   for (int i = 0; i < 6; ++i) g[i] = 0.0;
-  for_each_obs<PLANAR>(tv, [&](const Obs& o) {
+#ifndef CAMCAL_REFINE_WALK
+#define CAMCAL_REFINE_WALK for_each_obs
+#endif
+  CAMCAL_REFINE_WALK<PLANAR>(tv, [&](const Obs& o) {
     double Yr[3], Yc[3];
     transform_point<PLANAR>(R, t, o.X, o.Y, o.Z, Yr, Yc);
     PointEval<MODEL> p;

@@ -19,6 +19,15 @@
 
 using namespace camcal;
 
+// The loops over tiles / poses run on all host cores when the file is built with -fopenmp (the oracle's
+// CPU-baseline build, oracle/Makefile: libcamcal_cpu.so); the tests' build is serial.  Either way sums are
+// formed per tile and added up in tile order, so results do not depend on the number of threads.
+#ifdef _OPENMP
+#define CC_OMP_FOR _Pragma("omp parallel for schedule(dynamic, 1)")
+#else
+#define CC_OMP_FOR
+#endif
+
 namespace {
 inline LaneTile lane_tile(const camcal_tiles* t, int tile, int lane) {
   LaneTile tv;
@@ -36,8 +45,11 @@ void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, 
                  double* Vb, double* gb) {
   constexpr bool NORMAL = MODE > 0;
   constexpr int NV = IntrAcc<MODEL>::NV, NR = IntrAcc<MODEL>::NR;
-  std::vector<double> tot(NR, 0.0);
+  // partial sums per tile, added up in tile order: the same result for every thread count
+  std::vector<double> part((size_t)t->n_tiles * NR, 0.0), tot(NR, 0.0);
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile) {
+    double* pt = part.data() + (size_t)tile * NR;
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
       double p[6];
@@ -52,9 +64,11 @@ void intr_normal(const camcal_tiles* t, const double* intr, const double* pose, 
         for (int e = 0; e < 21; ++e) Vb[e * t->n_slots + slot] = V[e];
         for (int e = 0; e < 6; ++e) gb[e * t->n_slots + slot] = g[e];
       }
-      for (int i = 0; i < NR; ++i) tot[i] += acc.v[i];
+      for (int i = 0; i < NR; ++i) pt[i] += acc.v[i];
     }
   }
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int i = 0; i < NR; ++i) tot[i] += part[(size_t)tile * NR + i];
   if (NORMAL) IntrAcc<MODEL>::expand(tot.data(), glob);
   else glob[NV - 1] = tot[IntrAcc<MODEL>::COST];
 }
@@ -63,6 +77,7 @@ template <int MODEL>
 void view_blocks(const camcal_tiles* t, const double* intr, const double* pose, double* V, double* W, double* g) {
   constexpr int NI = MT<MODEL>::NI;
   const int64_t S = t->n_slots;
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -80,36 +95,44 @@ void view_blocks(const camcal_tiles* t, const double* intr, const double* pose, 
 template <int NI>
 void schur(const camcal_tiles* t, const double* V, const double* W, const double* g, double lam, double* out) {
   constexpr int NV = trisz(NI) + NI;
-  double acc[NV];
-  for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-  for (int64_t slot = 0; slot < t->n_slots; ++slot)
-    if (t->lane_n[slot] > 0) lane_schur<NI>(V, W, g, t->n_slots, slot, lam, acc);
-  for (int i = 0; i < NV; ++i) out[i] = acc[i];
+  std::vector<double> part((size_t)t->n_tiles * NV, 0.0);
+  CC_OMP_FOR
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int64_t slot = (int64_t)tile * LANES; slot < (int64_t)(tile + 1) * LANES; ++slot)
+      if (t->lane_n[slot] > 0) lane_schur<NI>(V, W, g, t->n_slots, slot, lam, part.data() + (size_t)tile * NV);
+  for (int i = 0; i < NV; ++i) out[i] = 0.0;
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int i = 0; i < NV; ++i) out[i] += part[(size_t)tile * NV + i];
 }
 
 template <int NI>
 void backsub(const camcal_tiles* t, const double* V, const double* W, const double* g, double lam, const double* dK,
              const double* pin, double* pout, double* norms) {
   const int64_t S = t->n_slots;
-  double a0 = 0, a1 = 0;
-  for (int64_t slot = 0; slot < S; ++slot) {
-    double prev[6], out[6];
-    load_pose(pin, S, slot, prev);
-    if (t->lane_n[slot] > 0) {
-      double dd, pp;
-      lane_backsub<NI>(V, W, g, S, slot, lam, dK, prev, out, dd, pp);
-      a0 += dd; a1 += pp;
-    } else {
-      for (int c = 0; c < 6; ++c) out[c] = prev[c];
+  std::vector<double> part((size_t)t->n_tiles * 2, 0.0);
+  CC_OMP_FOR
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int64_t slot = (int64_t)tile * LANES; slot < (int64_t)(tile + 1) * LANES; ++slot) {
+      double prev[6], out[6];
+      load_pose(pin, S, slot, prev);
+      if (t->lane_n[slot] > 0) {
+        double dd, pp;
+        lane_backsub<NI>(V, W, g, S, slot, lam, dK, prev, out, dd, pp);
+        part[(size_t)tile * 2] += dd; part[(size_t)tile * 2 + 1] += pp;
+      } else {
+        for (int c = 0; c < 6; ++c) out[c] = prev[c];
+      }
+      for (int c = 0; c < 6; ++c) pout[c * S + slot] = out[c];
     }
-    for (int c = 0; c < 6; ++c) pout[c * S + slot] = out[c];
-  }
+  double a0 = 0, a1 = 0;
+  for (int tile = 0; tile < t->n_tiles; ++tile) { a0 += part[(size_t)tile * 2]; a1 += part[(size_t)tile * 2 + 1]; }
   norms[0] = a0; norms[1] = a1;
 }
 
 template <int MODEL>
 void pose_refine(const camcal_tiles* t, const double* intr, double* pose, int max_iter, double tol, int32_t* iters) {
   const int64_t S = t->n_slots;
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -127,6 +150,7 @@ void pose_refine(const camcal_tiles* t, const double* intr, double* pose, int ma
 template <int MODEL>
 void pose_init(const camcal_tiles* t, const double* intr, double* pose, int32_t* status) {
   const int64_t S = t->n_slots;
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -142,8 +166,8 @@ static void cross_schur(const camcal_tiles* t, const double* intr, const double*
                         const double* gb, double lam, double* Wb, double* out) {
   constexpr int NI = MT<MODEL>::NI, NS = trisz(NI) + NI;
   const int64_t S = t->n_slots;
-  double acc[NS];
-  for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+  std::vector<double> part((size_t)t->n_tiles * NS, 0.0);
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -156,10 +180,12 @@ static void cross_schur(const camcal_tiles* t, const double* intr, const double*
         double V[21], g[6];
         for (int e = 0; e < 21; ++e) V[e] = Vb[e * S + slot];
         for (int e = 0; e < 6; ++e) g[e] = gb[e * S + slot];
-        lane_schur_regs<NI>(V, W, g, lam, acc);
+        lane_schur_regs<NI>(V, W, g, lam, part.data() + (size_t)tile * NS);
       }
     }
-  for (int i = 0; i < NS; ++i) out[i] = acc[i];
+  for (int i = 0; i < NS; ++i) out[i] = 0.0;
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int i = 0; i < NS; ++i) out[i] += part[(size_t)tile * NS + i];
 }
 // ---- rig (include/camcal.h "Multi-camera rig"): the same per-lane bodies, looped -------------
 template <int MODEL>
@@ -168,9 +194,10 @@ void rig_eval_cam(const camcal_rig* rg, int b, int cam, double* red) {
   const camcal_rig_cam& k = rg->cam[cam];
   const camcal_tiles* t = &k.tiles;
   const int64_t S = t->n_slots;
-  std::vector<double> tot(NR, 0.0);
+  std::vector<double> tot(NR, 0.0), part((size_t)t->n_tiles * NR, 0.0);
   const double* I = rg->intr[b] + cam * 16;
   const double* e = rg->ext[b] + cam * 6;
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -189,8 +216,10 @@ void rig_eval_cam(const camcal_rig* rg, int b, int cam, double* red) {
       for (int q = 0; q < 21; ++q) k.V[q * S + slot] = acc.V[q];
       for (int q = 0; q < NI * 6; ++q) k.W[q * S + slot] = acc.W[q];
       for (int q = 0; q < 6; ++q) k.g[q * S + slot] = acc.g[q];
-      for (int i = 0; i < NR; ++i) tot[i] += gacc.v[i];
+      for (int i = 0; i < NR; ++i) part[(size_t)tile * NR + i] += gacc.v[i];
     }
+  for (int tile = 0; tile < t->n_tiles; ++tile)
+    for (int i = 0; i < NR; ++i) tot[i] += part[(size_t)tile * NR + i];
   for (int i = 0; i < NR; ++i) red[i] = tot[i];
 }
 
@@ -199,12 +228,15 @@ void rig_assemble_cam(const camcal_rig* rg, int b, int cam, double* rec_ext) {
   constexpr int NACC = NI * 6 + 27;
   const camcal_rig_cam& k = rg->cam[cam];
   const int64_t S = k.tiles.n_slots, P = rg->P;
-  double acc[NACC];
-  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  const int64_t nch = (S + 63) / 64;
+  std::vector<double> part((size_t)nch * NACC, 0.0);
   double* Vp = rg->Vp[b] + (int64_t)cam * 21 * P;
   double* gp = rg->gp[b] + (int64_t)cam * 6 * P;
   double* Wp = rg->Wp[b] + (int64_t)cam * (NI + 6) * 6 * P;
-  for (int64_t slot = 0; slot < S; ++slot) {
+  CC_OMP_FOR
+  for (int64_t ch = 0; ch < nch; ++ch)
+  for (int64_t slot = ch * 64; slot < (ch + 1) * 64 && slot < S; ++slot) {
+    double* acc = part.data() + (size_t)ch * NACC;
     const int idx = k.slot_pose[slot];
     if (idx < 0) continue;
     double pp[6], Vl[21], Wl[NI * 6], gl[6], oV[21], og[6], oW[(NI + 6) * 6];
@@ -220,12 +252,15 @@ void rig_assemble_cam(const camcal_rig* rg, int b, int cam, double* rec_ext) {
     for (int i = 0; i < 6; ++i) gp[i * P + idx] = og[i];
     for (int i = 0; i < (NI + 6) * 6; ++i) Wp[i * P + idx] = oW[i];
   }
-  for (int i = 0; i < NACC; ++i) rec_ext[i] = acc[i];
+  for (int i = 0; i < NACC; ++i) rec_ext[i] = 0.0;
+  for (int64_t ch = 0; ch < nch; ++ch)
+    for (int i = 0; i < NACC; ++i) rec_ext[i] += part[(size_t)ch * NACC + i];
 }
 
 template <int G>
 void rig_pose_schur(int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp, double lam, double* Yt,
                     double* z) {
+  CC_OMP_FOR
   for (int64_t p = 0; p < P; ++p) {
     double U[21], g[6];
     double id[6];
@@ -244,8 +279,13 @@ void rig_pose_schur(int n_cams, int64_t P, const double* Vp, const double* gp, c
 template <int G>
 void rig_backsub(int n_cams, int64_t P, const double* Vp, const double* gp, const double* Wp, double lam,
                  const double* dG, const double* pin, double* pout, double* norms) {
-  double a0 = 0, a1 = 0;
-  for (int64_t p = 0; p < P; ++p) {
+  const int64_t nch = (P + 63) / 64;
+  std::vector<double> part((size_t)nch * 2, 0.0);
+  CC_OMP_FOR
+  for (int64_t ch = 0; ch < nch; ++ch)
+  for (int64_t p = ch * 64; p < (ch + 1) * 64 && p < P; ++p) {
+    double& a0 = part[(size_t)ch * 2];
+    double& a1 = part[(size_t)ch * 2 + 1];
     double U[21], rhs[6];
     double id[6];
     const bool ok = rig_pose_factor<G>(n_cams, Vp, gp, P, p, lam, U, rhs, id);
@@ -262,7 +302,9 @@ void rig_backsub(int n_cams, int64_t P, const double* Vp, const double* gp, cons
       a0 += d * d; a1 += prev * prev;
     }
   }
-  norms[0] = a0; norms[1] = a1;
+  double s0 = 0, s1 = 0;
+  for (int64_t ch = 0; ch < nch; ++ch) { s0 += part[(size_t)ch * 2]; s1 += part[(size_t)ch * 2 + 1]; }
+  norms[0] = s0; norms[1] = s1;
 }
 }  // namespace
 
@@ -272,11 +314,13 @@ void fused_response(const camcal_tiles* t, const double* intr, const double* pos
                     double* schur_out) {
   constexpr int NI = MT<MODEL>::NI, NR = IntrAcc<MODEL>::NR, NS = trisz(NI) + NI;
   const int64_t S = t->n_slots;
-  std::vector<double> tot(NR, 0.0);
+  std::vector<double> tot(NR, 0.0), part((size_t)t->n_tiles * (NR + NS), 0.0);
   double sacc[NS];
   for (int i = 0; i < NS; ++i) sacc[i] = 0.0;
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
+      double* pt = part.data() + (size_t)tile * (NR + NS);
       const int64_t slot = (int64_t)tile * LANES + lane;
       const LaneTile tv = lane_tile(t, tile, lane);
       double p[6];
@@ -286,13 +330,18 @@ void fused_response(const camcal_tiles* t, const double* intr, const double* pos
       gacc.zero();
       if (t->planar) lane_normal_fused<MODEL, true>(tv, intr, p, acc, gacc);
       else lane_normal_fused<MODEL, false>(tv, intr, p, acc, gacc);
-      for (int i = 0; i < NR; ++i) tot[i] += gacc.v[i];
+      for (int i = 0; i < NR; ++i) pt[i] += gacc.v[i];
       if (tv.n <= 0) continue;
       double id[6];
-      lane_schur_regs<NI>(acc.V, acc.W, acc.g, 0.0, sacc, id);
+      lane_schur_regs<NI>(acc.V, acc.W, acc.g, 0.0, pt + NR, id);
       lane_pose_response<NI>(acc.V, id, acc.W);
       for (int e = 0; e < NI * 6; ++e) Y[e * S + slot] = acc.W[e];
     }
+  for (int tile = 0; tile < t->n_tiles; ++tile) {
+    const double* pt = part.data() + (size_t)tile * (NR + NS);
+    for (int i = 0; i < NR; ++i) tot[i] += pt[i];
+    for (int i = 0; i < NS; ++i) sacc[i] += pt[NR + i];
+  }
   IntrAcc<MODEL>::expand(tot.data(), glob);
   for (int i = 0; i < NS; ++i) schur_out[i] = sacc[i];
 }
@@ -340,6 +389,7 @@ int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, 
 
 int camcal_pack_tiles(const float* obj, const float* img, const int64_t* view_ptr, const int32_t* slot_view,
                       const camcal_tiles* t, float* out, void*) {
+  CC_OMP_FOR
   for (int tile = 0; tile < t->n_tiles; ++tile)
     for (int lane = 0; lane < LANES; ++lane) {
       const int64_t slot = (int64_t)tile * LANES + lane;
@@ -433,6 +483,7 @@ int camcal_pose_predict(int model, const camcal_tiles* t, const double* Y, const
   const int64_t S = t->n_slots;
   double s[9];
   for (int a = 0; a < ni; ++a) s[a] = -scale * dK[a];
+  CC_OMP_FOR
   for (int64_t slot = 0; slot < S; ++slot) {
     if (t->lane_n[slot] <= 0 || (iters && (iters[slot] == 0 || iters[slot] >= cap))) continue;
     double p[6];
@@ -519,6 +570,7 @@ int camcal_rig_eliminate(const camcal_rig* rg, int b, double lam, void*) {
   double* Cm = rg->rec[b] + L.o_C;
   double* d = rg->rec[b] + L.o_d;
   const int n = L.n;
+  CC_OMP_FOR
   for (int i = 0; i < n; ++i) {
     for (int j = i; j < n; ++j) {
       double s = 0.0;
