@@ -59,12 +59,14 @@ def pmc_profile(n_obs):
     (profiles/pmc_traffic.json, collected by tools/pmc_run.py; PMC cannot be read from inside this
     process), scaled by observation count.  Values are None when the file is absent and flagged stale
     when the kernel sources changed since the passes were taken."""
-    out = {"traffic": None, "executed_flop_per_obs": None, "stale": None, "source": None}
+    out = {"traffic": None, "executed_flop_per_obs": None, "stale": None, "source": None, "counters": None}
     try:
         tj = json.load(open(os.path.join(HERE, "profiles", "pmc_traffic.json")))
         k = tj["k_normal_fused<fisheye,no block stores,planar>"]
         out["traffic"] = k["hbm_bytes"] * n_obs / tj["workload_obs"]
         out["executed_flop_per_obs"] = k.get("executed_flop_per_obs")
+        out["counters"] = {c: k[c] for c in ("valu_busy_of_wave_cycles", "lane_utilisation",
+                                             "fp64_share_of_valu_instructions") if c in k} or None
         out["stale"] = tj.get("kernel_source_sha") != kernel_source_sha()
         out["source"] = tj.get("source")
     except Exception:
@@ -214,13 +216,11 @@ def solve_times(dev, with_cpu=True):
         P = synth.config("C1")
         o, i = P.as_lists()
 
-        def c1():
-            info = {}
-            cc.calibrateCamera(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1, criteria=crit,
-                               _info=info)
+        def c1(info=None):          # the plain drop-in call: the one-call path (camcal_calibrate)
+            cc.calibrateCamera(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=1, criteria=crit, _info=info)
             return info
-        ms, info = med(c1)
-        out["C1_pinhole_20x54"] = {"ms": ms, "iterations": info["iters"]}
+        ms, _ = med(c1)
+        out["C1_pinhole_20x54"] = {"ms": ms, "iterations": c1({})["iters"]}
         if with_cpu:
             from oracle import cvcalib as O
             t0 = time.perf_counter()
@@ -230,13 +230,12 @@ def solve_times(dev, with_cpu=True):
         P2 = synth.config("C2")
         o2, i2 = P2.as_lists()
 
-        def c2():
-            info = {}
+        def c2(info=None):
             cc.fisheye.calibrate(o2, i2, P2.image_size, P2.K_guess.copy(), P2.D_guess.copy(), flags=fe,
                                  criteria=crit, _info=info)
             return info
-        ms, info = med(c2)
-        out["C2_fisheye_500x88"] = {"ms": ms, "iterations": info["iters"]}
+        ms, _ = med(c2)
+        out["C2_fisheye_500x88"] = {"ms": ms, "iterations": c2({})["iters"]}
         if with_cpu:
             t0 = time.perf_counter()
             O.fisheye_calibrate(o2, i2, P2.image_size, P2.K_guess, P2.D_guess, flags=fe, criteria=crit, solver="schur")
@@ -692,6 +691,11 @@ def main():
                 "executed_flop_per_obs": ex_flop, "achieved_executed": ex_tf,
                 "frac_executed": (ex_tf / PEAK_FP64_TFLOPS) if ex_tf else None,
                 "traffic_source": pmc["source"], "traffic_stale": pmc["stale"],
+                # why frac_executed stops where it does (committed PMC passes): the one resident wavefront keeps the
+                # VALU busy for valu_busy of its cycles with every lane active; fp64_share of the issue slots are
+                # FP64 instructions (the rest: v_accvgpr moves of the 112 accumulators that do not fit 128 doubles
+                # of architectural VGPRs, address / loop code); DESIGN.md section 4 has the table
+                "counters": pmc["counters"],
             },
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gb, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": ach_gb / PEAK_HBM_GBS, "traffic": traffic, "traffic_stale": pmc["stale"],

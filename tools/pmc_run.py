@@ -24,6 +24,8 @@ lib.camcal_peak_probe(1, buf.data_ptr(), buf.numel(), 1, None, C.byref(res))   #
 for _ in range(3):
     E.normal_eq(0, 0, 0.0, store_blocks=False, fused=True)
 for _ in range(3):
+    E.normal_eq_response(0, 0)              # the form the fisheye loop runs since round 3: + V^-1 W^T per view (384 B)
+for _ in range(3):
     E.normal_eq(0, 0, 0.0, store_blocks=True, fused=False)
 # pose re-estimation: from the homography initialisation (the first refinement of a solve)
 E.pose_init(0, 0)

@@ -9,7 +9,7 @@ for f in sorted(glob.glob(d + '/*counter_collection.csv')):
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        m = re.search(r'(k_[a-z_0-9]+)(<[^>]*>)?', k)
+        m = re.search(r'(k_[a-z_0-9]+)(<[^>]*>)?', k)  # the template arguments tell the instantiations apart
         if 'anonymous namespace' not in k or not m or m.group(1) not in KERN:
             continue
         name = m.group(1) + (m.group(2) or '')
