@@ -160,6 +160,25 @@ def _gather_views(object_points, image_points, min_points=4):
     return view_ptr, obj, img
 
 
+def _gather_collectively(object_points, image_points, comm):
+    """_gather_views; in a multi-rank call a shard that is rejected (a view with three corners, mismatched
+    lists) makes EVERY rank raise, not only the one that holds it -- the others would otherwise wait in the
+    first collective of the solve for a rank that has left."""
+    if not comm.enabled:
+        return _gather_views(object_points, image_points)
+    exc = None
+    try:
+        out = _gather_views(object_points, image_points)
+    except error as e:
+        exc, out = e, None
+    n_bad = comm.total(0.0 if exc is None else 1.0, _resolve()[1])
+    if exc is not None:
+        raise exc
+    if n_bad > 0:
+        raise error("the view lists of another rank were rejected")
+    return out
+
+
 def _write_back(dst, values):
     """cv2 InputOutputArray: write into the caller's array when it is a
     float64 ndarray of matching size, and return the array handed back."""
@@ -477,8 +496,8 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     """
     flags = int(flags)
     D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
-    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
     comm = _comm or _solver.Comm()
+    view_ptr, obj, img = _gather_collectively(objectPoints, imagePoints, comm)
     if _info is None and not comm.enabled:
         # the plain call: everything behind one library entry point (camcal_calibrate)
         rms, K9, D5, rt, _ = _one_call(_lib.PINHOLE, view_ptr, obj, img, imageSize, _k9(intr0), intr0[4:9].copy(), D.size,
@@ -559,8 +578,8 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
     """
     flags = int(flags)
     intr0, mask = _prep_fisheye(K, D, flags)
-    view_ptr, obj, img = _gather_views(objectPoints, imagePoints)
     comm = _comm or _solver.Comm()
+    view_ptr, obj, img = _gather_collectively(objectPoints, imagePoints, comm)
     if _info is None and not comm.enabled:
         D4 = np.asarray(D, dtype=np.float64).ravel().copy()
         rms, K9, D4, rt, _ = _one_call(_lib.FISHEYE, view_ptr, obj, img, image_size, _k9(intr0), D4, 4, flags, criteria)

@@ -97,7 +97,6 @@ struct Solve {
   const camcal_comm* comm = nullptr;
   void* stream = nullptr;
   int rc = 0;
-  bool active = false;
   // layout
   int32_t T = 0;
   int64_t S = 0, total_floats = 0, n_obs = 0;
@@ -110,7 +109,7 @@ struct Solve {
   std::unique_ptr<camcal_drv::FisheyeGN> gn;
   std::unique_ptr<camcal_drv::PinholeLM> lm;
   // results
-  std::vector<double> h_intr, h_pose, h_tot;
+  std::vector<double> h_intr, h_pose;
   std::vector<int32_t> h_status;
 
   char* ws() const { return (char*)p->workspace; }
@@ -227,8 +226,25 @@ struct Solve {
       lm->mask_host = mask; lm->max_iter = max_iter; lm->eps = eps; lm->comm = comm; lm->stream = stream;
       if (!lm->args_ok()) return CAMCAL_E_BADARG;
     }
-    active = true;
     return 0;
+  }
+
+  // Multi-rank call: did the set-up succeed on EVERY rank?  A shard can be rejected for reasons the other
+  // ranks do not share (a view with three corners, a workspace that is too small); without this exchange
+  // they would wait in the loop's first all-reduce for a rank that has already returned.
+  int agree_on_setup(int rc_setup) {
+    if (!comm) return rc_setup;
+    double* d = nullptr;
+    if (gn || lm) d = at<double>(c.stats);
+    else if (p->workspace && p->workspace_bytes >= 256 && ((uintptr_t)p->workspace & (ALIGN - 1)) == 0) d = (double*)p->workspace;
+    if (!d) return rc_setup ? rc_setup : CAMCAL_E_BADARG;      // no device memory at all to take part with (documented)
+    double failed = rc_setup ? 1.0 : 0.0;
+    CAMCAL_DRV_TRY(camcal_upload(d, &failed, sizeof(failed), stream));
+    CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, d, 1, stream));
+    CAMCAL_DRV_TRY(camcal_download(&failed, d, sizeof(failed), stream));
+    CAMCAL_DRV_TRY(camcal_stream_sync(stream));
+    if (rc_setup) return rc_setup;
+    return failed != 0.0 ? CAMCAL_E_PEER : 0;
   }
 
   bool done() const { return gn ? gn->done() : lm ? lm->done() : true; }
@@ -292,7 +308,7 @@ inline void fail(camcal_problem* p, int rc) {
 // one problem from its host arrays to the point where its results sit in host staging: set-up, loop,
 // read-back, drained stream.  rc: the solve's own status; the return value: whether the read-back worked
 inline int run_to_readback(Solve& s) {
-  s.rc = s.setup();
+  s.rc = s.agree_on_setup(s.setup());
   if (s.rc == 0) {
     while (!s.done()) {
       int rc = s.launch();
@@ -300,7 +316,7 @@ inline int run_to_readback(Solve& s) {
       if (rc) { s.rc = rc; break; }
     }
   }
-  if (!(s.gn || s.lm)) return 0;               // rejected before any device work
+  if (!(s.gn || s.lm) || s.rc == CAMCAL_E_PEER) return 0;   // rejected before any device work / with the other ranks
   int rc = s.collect_begin();                  // got as far as the device: read back what there is
   if (rc == 0) rc = camcal_stream_sync(s.stream);
   return rc;
@@ -334,6 +350,8 @@ int camcal_calibrate_many(camcal_problem* problems, int n, void* stream) {
   // independent problems: one stream each (at most CAMCAL_RIG_MAX_CAMS distinct ones, shared round robin beyond)
   void* side[CAMCAL_RIG_MAX_CAMS];
   const int n_streams = n < CAMCAL_RIG_MAX_CAMS ? n : CAMCAL_RIG_MAX_CAMS;
+  int dev = 0;
+  CAMCAL_DRV_TRY(camcal_get_device(&dev));
   CAMCAL_DRV_TRY(camcal_fork_streams(stream, n_streams, side));
   for (int i = 0; i < n; ++i) {
     std::unique_ptr<Solve> s(new Solve());
@@ -342,8 +360,6 @@ int camcal_calibrate_many(camcal_problem* problems, int n, void* stream) {
     problems[i].status = 0;
     sv.push_back(std::move(s));
   }
-  int dev = 0;
-  CAMCAL_DRV_TRY(camcal_get_device(&dev));
   std::vector<int> rb((size_t)n, 0);
   auto work = [&](int i, bool own_thread) {
     if (own_thread && camcal_set_device(dev) != 0) { sv[(size_t)i]->rc = CAMCAL_E_BADARG; return; }
@@ -351,15 +367,20 @@ int camcal_calibrate_many(camcal_problem* problems, int n, void* stream) {
   };
   {
     std::vector<std::thread> th;
-    for (int i = 1; i < n; ++i) th.emplace_back(work, i, true);
+    int started = 1;                               // problem 0 runs on the calling thread
+    try {
+      for (; started < n; ++started) th.emplace_back(work, started, true);
+    } catch (...) {                                // no more threads to be had: the rest runs here, after problem 0
+    }
     work(0, false);
+    for (int i = started; i < n; ++i) work(i, false);
     for (auto& t : th) t.join();
   }
   int first = camcal_join_streams(stream, n_streams, side);
   for (int i = 0; i < n; ++i) {
     Solve& s = *sv[(size_t)i];
     int rc = s.rc;
-    if (s.gn || s.lm) rc = rb[(size_t)i] ? (s.rc ? s.rc : rb[(size_t)i]) : s.collect_end(s.rc);
+    if ((s.gn || s.lm) && s.rc != CAMCAL_E_PEER) rc = rb[(size_t)i] ? (s.rc ? s.rc : rb[(size_t)i]) : s.collect_end(s.rc);
     if (rc) camcal_cal::fail(s.p, rc);
     if (rc && !first) first = rc;
   }
@@ -384,7 +405,8 @@ int camcal_calibrate(int model, int64_t n_views, const int64_t* view_ptr_host, c
   s.stream = stream;
   const int rb = camcal_cal::run_to_readback(s);
   int rc = s.rc;
-  if (s.gn || s.lm) rc = rb ? (rc ? rc : rb) : s.collect_end(rc);   // (rejected before any device work: every rank rejects alike)
+  if ((s.gn || s.lm) && rc != CAMCAL_E_PEER) rc = rb ? (rc ? rc : rb) : s.collect_end(rc);
+  if (rc) camcal_cal::fail(&p, rc);
   *rms_out_host = p.rms;
   *iterations_out_host = p.iterations;
   return rc;

@@ -355,8 +355,10 @@ int64_t camcal_workspace_len(int model, int64_t n_views, const int64_t* view_ptr
 
 /* One calibration.  With a communicator every rank calls it with its own shard of the views
  * and the same guess: the records are summed inside the loop, rms is over all ranks, every
- * rank receives the same K, D and the poses of its own views; a degenerate view on any rank
- * fails the call on every rank (CAMCAL_E_NUMERIC where it lives, CAMCAL_E_PEER elsewhere). */
+ * rank receives the same K, D and the poses of its own views; a shard that is rejected (bad
+ * arguments, workspace too small) or a degenerate view on any rank fails the call on every rank
+ * (its own code where it happened, CAMCAL_E_PEER elsewhere) -- provided every rank passes at
+ * least 256 bytes of aligned device workspace to exchange that verdict through. */
 int camcal_calibrate(int model, int64_t n_views, const int64_t* view_ptr_host, const float* obj_host,
                      const float* img_host, int width, int height, double* K_host, double* D_host,
                      int n_dist, double* rt_host, int32_t* view_status_host, int flags, int crit_type,

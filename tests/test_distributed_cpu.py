@@ -126,3 +126,76 @@ def test_degenerate_view_on_one_rank_raises_on_every_rank(emu, tmp_path):
     for r in range(2):
         msgs = open(tmp_path / f"d{r}.txt").read().split("\n")
         assert len(msgs) == 2 and all(m != "no error" for m in msgs), (r, msgs)
+
+
+def _worker_one_call(rank, world, port, out_dir):
+    """camcal_calibrate (the one-call C entry) with a communicator on this rank's shard of the views: same K, D,
+    rms as the single-rank call; and a shard that is rejected on one rank only (a view with three corners)
+    fails the call on BOTH ranks instead of leaving the other in the loop's first all-reduce."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cameracalibration_amd import _lib, synth
+    from cameracalibration_amd.distributed import shard_ranges
+    lib = _lib.load(EMU)
+    res = {}
+    for name, mid, nd, flags in (("C3", 1, 4, 8 | 2 | 1), ("C1", 0, 5, 1)):
+        P = synth.config(name, n_views=40)
+        n = np.diff(P.view_ptr)
+        lo, hi = shard_ranges(n, world)[rank]
+        vp = (P.view_ptr[lo:hi + 1] - P.view_ptr[lo]).astype(np.int64)
+        obj = np.ascontiguousarray(P.obj.numpy()[P.view_ptr[lo]:P.view_ptr[hi]])
+        img = np.ascontiguousarray(P.img.numpy()[P.view_ptr[lo]:P.view_ptr[hi]])
+        for bad in (False, True):
+            vpb = vp.copy()
+            if bad and rank == 1:
+                vpb[-1] = vpb[-2] + 3                                 # the last view of rank 1 keeps three corners
+            nbytes = lib.camcal_workspace_len(mid, len(vpb) - 1, vpb.ctypes.data)
+            ws = torch.empty(nbytes // 8 + 64, dtype=torch.float64)
+            base = (ws.data_ptr() + 255) & ~255
+
+            def cb(ctx, buf, cnt, stream, ws=ws):
+                off = (int(buf) - ws.data_ptr()) // 8
+                dist.all_reduce(ws[off:off + cnt])
+                return 0
+            fn = _lib.ALLREDUCE_FN(cb)
+            comm = _lib.CommStruct(fn, None)
+            K = np.array([P.K_guess[0, 0], 0, P.K_guess[0, 2], 0, P.K_guess[1, 1], P.K_guess[1, 2], 0, 0, 1.0])
+            D = np.zeros(5)
+            D[:nd] = P.D_guess.ravel()
+            rt = np.zeros((len(vpb) - 1, 6))
+            rms, its = C.c_double(0), C.c_int32(0)
+            rc = lib.camcal_calibrate(mid, len(vpb) - 1, vpb.ctypes.data, obj.ctypes.data, img.ctypes.data, P.image_size[0],
+                                      P.image_size[1], K.ctypes.data, D.ctypes.data, nd, rt.ctypes.data, None, flags, 3, 1000,
+                                      1e-6, base, ws.numel() * 8 - (base - ws.data_ptr()), C.byref(comm), None,
+                                      C.byref(rms), C.byref(its))
+            res["%s_%s" % (name, "bad" if bad else "ok")] = np.array([rc, rms.value, its.value] + K.tolist() + D.tolist())
+            if not bad:
+                res["%s_rt" % name] = rt
+    t = torch.ones(1)
+    dist.all_reduce(t)                       # still in step
+    assert t.item() == world
+    np.savez(os.path.join(out_dir, f"o{rank}.npz"), **res)
+    dist.destroy_process_group()
+
+
+def test_one_call_entry_with_a_communicator(emu, tmp_path):
+    mp.spawn(_worker_one_call, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    import cameracalibration_amd as cc
+    from cameracalibration_amd import synth
+    parts = [np.load(tmp_path / f"o{r}.npz") for r in range(2)]
+    for name, fn, fl in (("C3", cc.fisheye.calibrate, 8 | 2 | 1), ("C1", cc.calibrateCamera, 1)):
+        P = synth.config(name, n_views=40)
+        objs, imgs = P.as_lists()
+        ref = fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=(3, 1000, 1e-6))
+        for p in parts:
+            r = p[name + "_ok"]
+            assert r[0] == 0 and abs(r[1] - ref[0]) < 1e-10
+            assert np.allclose(r[3:12].reshape(3, 3), ref[1], rtol=1e-10)
+            assert np.allclose(r[12:12 + ref[2].size], ref[2].ravel(), rtol=1e-8, atol=1e-13)
+        rt = np.concatenate([p[name + "_rt"] for p in parts])
+        assert np.allclose(rt[:, :3], np.hstack(ref[3]).T, atol=1e-9) and np.allclose(rt[:, 3:], np.hstack(ref[4]).T, atol=1e-7)
+        assert parts[1][name + "_bad"][0] == -1 and parts[0][name + "_bad"][0] == -7      # BADARG where it is, PEER elsewhere
