@@ -201,10 +201,15 @@ def solve_times(dev, with_cpu=True):
     fe = cc.fisheye.CALIB_FIX_SKEW | cc.fisheye.CALIB_RECOMPUTE_EXTRINSIC | cc.CALIB_USE_INTRINSIC_GUESS
     crit = (3, 1000, 1e-6)
 
-    def med(fn):
+    def med(fn, reps=9, warm_s=0.05):
+        # steady state: the CPU legs between these measurements leave the device idle for seconds, and a
+        # millisecond call right after that is timed at idle clocks; so repeat the call for warm_s first
+        t_end = time.perf_counter() + warm_s
         fn()
+        while time.perf_counter() < t_end:
+            fn()
         ts = []
-        for _ in range(3):
+        for _ in range(reps):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             info = fn()

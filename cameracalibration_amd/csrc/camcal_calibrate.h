@@ -20,6 +20,9 @@
 //       (asynchronous, ordered on the stream; the host side must stay valid until the sync)
 //   int camcal_stream_sync(void* stream)
 //   int camcal_get_device(int* dev) / int camcal_set_device(int dev)   (a new host thread starts on device 0)
+//   void* camcal_pinned_take(size_t bytes) / void camcal_pinned_give(void*)
+//       (page-locked host staging from a pool that lives as long as the process; NULL: none to be had, the
+//        copies then go from / to the caller's arrays directly)
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -44,53 +47,63 @@ constexpr int FE_USE_GUESS = 1, FE_RECOMPUTE = 2, FE_CHECK_COND = 4, FE_FIX_SKEW
 constexpr size_t ALIGN = 256;
 inline size_t up(size_t x) { return (x + ALIGN - 1) & ~(ALIGN - 1); }
 
-// Byte offsets of the pieces of a workspace.
+// Byte offsets of the pieces of a workspace.  The host-filled pieces form one block
+// [tile_off | view_ptr | slot_view | lane_n | tile_nmax | img | obj | intr0] (one upload from pinned staging
+// for production-sized calls) and the results one block [intr0 | pose0 | status] (one download).
 struct Carve {
-  size_t head = 0;                     // [intr0 (16 doubles) | tile_off | view_ptr | slot_view | lane_n | tile_nmax]: one upload
-  size_t tile_off = 0, view_ptr = 0, slot_view = 0, lane_n = 0, tile_nmax = 0, head_bytes = 0;
-  size_t obj = 0, img = 0, pts = 0;
-  size_t intr1 = 0, pose0 = 0, pose1 = 0, V0 = 0, V1 = 0, g0 = 0, g1 = 0, W = 0, rec = 0, glob1 = 0, dK = 0, stats = 0,
-         scratch = 0, status = 0, iters = 0;
+  size_t tile_off = 0, view_ptr = 0, slot_view = 0, lane_n = 0, tile_nmax = 0, tables_bytes = 0;
+  size_t img = 0, obj = 0, intr0 = 0, up_bytes = 0;
+  size_t pose0 = 0, status = 0, res_bytes = 0;
+  size_t pts = 0;
+  size_t intr1 = 0, pose1 = 0, V0 = 0, V1 = 0, g0 = 0, g1 = 0, W = 0, rec = 0, glob1 = 0, dK = 0, stats = 0,
+         scratch = 0, iters = 0;
   size_t total = 0;
 };
+
+inline size_t up8(size_t x) { return (x + 7) & ~(size_t)7; }
 
 inline Carve carve(int model, int64_t n_views, int64_t n_obs, int32_t T, int64_t S, int64_t total_floats) {
   const int ni = camcal_n_intr(model), ng = camcal_glob_len(model), ns = camcal_schur_len(model);
   Carve c;
   size_t o = 0;
-  c.head = o;
-  o += 16 * sizeof(double);
   c.tile_off = o; o += (size_t)T * 8;
   c.view_ptr = o; o += (size_t)(n_views + 1) * 8;
   c.slot_view = o; o += (size_t)S * 4;
   c.lane_n = o; o += (size_t)S * 4;
   c.tile_nmax = o; o += (size_t)T * 4;
-  c.head_bytes = o;
+  c.tables_bytes = o;
+  o = up8(o);
+  c.img = o; o += (size_t)n_obs * 8;
+  c.obj = o; o = up8(o + (size_t)n_obs * 12);
+  c.intr0 = o; o += 16 * sizeof(double);
+  c.up_bytes = o;
+  c.pose0 = o; o += 6 * (size_t)S * sizeof(double);
+  c.status = o; o += (size_t)S * 4;
+  c.res_bytes = o - c.intr0;
   o = up(o);
-  c.obj = o; o = up(o + (size_t)n_obs * 12);
-  c.img = o; o = up(o + (size_t)n_obs * 8);
   c.pts = o; o = up(o + (size_t)(total_floats > 0 ? total_floats : 1) * 4);
   auto dbl = [&](size_t n) { const size_t at = o; o = up(o + n * sizeof(double)); return at; };
-  c.intr1 = dbl(16);
-  c.pose0 = dbl(6 * (size_t)S);
   c.W = dbl((size_t)ni * 6 * S);       // pinhole: the cross blocks; fisheye: the pose response Y
   c.rec = dbl((size_t)(ng + ns));
   c.glob1 = dbl((size_t)ng + 2);       // + the two step norms right behind it (one message for a trial point)
   c.dK = dbl(16);
   c.stats = dbl(8);
   if (model == CAMCAL_PINHOLE) {       // CvLevMarq keeps a current and a trial point
-    c.pose1 = dbl(6 * (size_t)S);
+    c.intr1 = dbl(16 + 6 * (size_t)S);
+    c.pose1 = c.intr1 + 16 * sizeof(double);
     c.V0 = dbl(21 * (size_t)S);
     c.V1 = dbl(21 * (size_t)S);
     c.g0 = dbl(6 * (size_t)S);
     c.g1 = dbl(6 * (size_t)S);
   }
   c.scratch = dbl((size_t)camcal_scratch_len(model, T));
-  c.status = o; o = up(o + (size_t)S * 4);
   c.iters = o; o = up(o + (size_t)S * 4);
   c.total = o;
   return c;
 }
+
+// pinned staging above this size is not worth its copy (and would pin gigabytes for the large sets)
+constexpr size_t PIN_LIMIT = (size_t)8 << 20;
 
 struct Solve {
   camcal_problem* p = nullptr;
@@ -100,7 +113,11 @@ struct Solve {
   // layout
   int32_t T = 0;
   int64_t S = 0, total_floats = 0, n_obs = 0;
-  std::vector<char> head;              // host image of the head block
+  std::vector<char> head;              // host image of the layout tables
+  double intr0[16];
+  void* pin = nullptr;                 // pinned staging for the one upload and the one download (or NULL: direct copies)
+  bool collecting = false;             // the result copies are on the stream
+  ~Solve() { if (pin) camcal_pinned_give(pin); }
   Carve c;
   camcal_tiles tiles{};
   uint8_t mask[9] = {1, 1, 1, 1, 1, 1, 1, 1, 1};
@@ -109,14 +126,13 @@ struct Solve {
   std::unique_ptr<camcal_drv::FisheyeGN> gn;
   std::unique_ptr<camcal_drv::PinholeLM> lm;
   // results
-  std::vector<double> h_intr, h_pose;
-  std::vector<int32_t> h_status;
+  std::vector<char> h_stage;            // [intr | pose | status] when there is no pinned staging
 
   char* ws() const { return (char*)p->workspace; }
   template <class Tp> Tp* at(size_t off) const { return (Tp*)(ws() + off); }
 
   // argument checks of the two cv2 calls, as the Python drop-in makes them (api.py: _prep_pinhole / _prep_fisheye)
-  int check(double intr0[16]) {
+  int check() {
     if (!p->view_ptr || !p->obj || !p->img || !p->K || !p->D || !p->rt || !p->workspace || p->n_views <= 0)
       return CAMCAL_E_BADARG;
     ni = camcal_n_intr(p->model);
@@ -164,8 +180,7 @@ struct Solve {
 
   // everything up to the first step of the loop, enqueued on the stream
   int setup() {
-    double intr0[16];
-    CAMCAL_DRV_TRY(check(intr0));
+    CAMCAL_DRV_TRY(check());
     const int64_t N = p->n_views;
     if (p->view_ptr[0] != 0) return CAMCAL_E_BADARG;
     std::vector<int32_t> n_per_view((size_t)N);
@@ -181,15 +196,26 @@ struct Solve {
     c = carve(p->model, N, n_obs, T, S, total_floats);
     if ((int64_t)c.total > p->workspace_bytes) return CAMCAL_E_TOOBIG;
     if (((uintptr_t)p->workspace & (ALIGN - 1)) != 0) return CAMCAL_E_BADARG;
-    head.assign(c.head_bytes, 0);
-    std::memcpy(head.data() + c.head, intr0, sizeof(intr0));
+    head.assign(c.tables_bytes, 0);
     CAMCAL_DRV_TRY(camcal_layout(N, n_per_view.data(), &T, &S, &total_floats, (int32_t*)(head.data() + c.slot_view),
                                  (int32_t*)(head.data() + c.lane_n), (int32_t*)(head.data() + c.tile_nmax),
                                  (int64_t*)(head.data() + c.tile_off)));
     std::memcpy(head.data() + c.view_ptr, p->view_ptr, (size_t)(N + 1) * 8);
-    CAMCAL_DRV_TRY(camcal_upload(ws() + c.head, head.data(), c.head_bytes, stream));
-    CAMCAL_DRV_TRY(camcal_upload(ws() + c.obj, p->obj, (size_t)n_obs * 12, stream));
-    CAMCAL_DRV_TRY(camcal_upload(ws() + c.img, p->img, (size_t)n_obs * 8, stream));
+    const size_t pin_bytes = c.up_bytes > c.res_bytes ? c.up_bytes : c.res_bytes;
+    if (pin_bytes <= PIN_LIMIT) pin = camcal_pinned_take(pin_bytes);
+    if (pin) {                                    // one block, one copy
+      char* u = (char*)pin;
+      std::memcpy(u, head.data(), c.tables_bytes);
+      std::memcpy(u + c.img, p->img, (size_t)n_obs * 8);
+      std::memcpy(u + c.obj, p->obj, (size_t)n_obs * 12);
+      std::memcpy(u + c.intr0, intr0, sizeof(intr0));
+      CAMCAL_DRV_TRY(camcal_upload(ws(), u, c.up_bytes, stream));
+    } else {
+      CAMCAL_DRV_TRY(camcal_upload(ws(), head.data(), c.tables_bytes, stream));
+      CAMCAL_DRV_TRY(camcal_upload(ws() + c.img, p->img, (size_t)n_obs * 8, stream));
+      CAMCAL_DRV_TRY(camcal_upload(ws() + c.obj, p->obj, (size_t)n_obs * 12, stream));
+      CAMCAL_DRV_TRY(camcal_upload(ws() + c.intr0, intr0, sizeof(intr0), stream));
+    }
     tiles.pts = at<float>(c.pts);
     tiles.tile_off = at<int64_t>(c.tile_off);
     tiles.tile_nmax = at<int32_t>(c.tile_nmax);
@@ -200,7 +226,7 @@ struct Solve {
     tiles.lanes_per_view = p->lanes_per_view;
     CAMCAL_DRV_TRY(camcal_pack_tiles(at<float>(c.obj), at<float>(c.img), at<int64_t>(c.view_ptr), at<int32_t>(c.slot_view),
                                      &tiles, at<float>(c.pts), stream));
-    double* intr = at<double>(c.head);
+    double* intr = at<double>(c.intr0);
     double* pose = at<double>(c.pose0);
     // cvFindExtrinsicCameraParams2 / CalibrateExtrinsics per view: homography start + refinement
     CAMCAL_DRV_TRY(camcal_pose_init(p->model, &tiles, intr, pose, at<int32_t>(c.status), stream));
@@ -251,18 +277,29 @@ struct Solve {
   int launch() { return gn ? gn->launch() : lm->launch(); }
   int finish() { return gn ? gn->finish() : lm->finish(); }
 
-  // results: enqueue the copies ...
+  // the loop has launched its last piece of work (the results on the device are final)
+  bool final_launched() const { return gn && gn->pending == camcal_drv::FisheyeGN::FINAL_COST; }
+
+  // results: enqueue the copies ([intr | pose | status], into the pinned staging when there is one) ...
+  const double* r_intr = nullptr;
+  const double* r_pose = nullptr;
+  const int32_t* r_status = nullptr;
   int collect_begin() {
+    if (collecting) return 0;
+    collecting = true;
     const int cur = lm ? lm->cur : 0;
-    h_intr.assign(16, 0.0);
-    h_pose.assign((size_t)6 * S, 0.0);
-    h_status.assign((size_t)S, 0);
-    const double* intr = cur ? at<double>(c.intr1) : at<double>(c.head);
-    const double* pose = cur ? at<double>(c.pose1) : at<double>(c.pose0);
-    CAMCAL_DRV_TRY(camcal_download(h_intr.data(), intr, 16 * sizeof(double), stream));
-    CAMCAL_DRV_TRY(camcal_download(h_pose.data(), pose, (size_t)6 * S * sizeof(double), stream));
-    CAMCAL_DRV_TRY(camcal_download(h_status.data(), at<int32_t>(c.status), (size_t)S * sizeof(int32_t), stream));
-    return 0;
+    const size_t pose_bytes = (size_t)6 * S * sizeof(double), st_bytes = (size_t)S * sizeof(int32_t);
+    char* dst = (char*)pin;
+    if (!dst) {
+      h_stage.assign(c.res_bytes, 0);
+      dst = h_stage.data();
+    }
+    r_intr = (const double*)dst;
+    r_pose = (const double*)(dst + 128);
+    r_status = (const int32_t*)(dst + 128 + pose_bytes);
+    if (cur == 0) return camcal_download(dst, ws() + c.intr0, c.res_bytes, stream);     // one block
+    CAMCAL_DRV_TRY(camcal_download(dst, ws() + c.intr1, 128 + pose_bytes, stream));
+    return camcal_download(dst + 128 + pose_bytes, ws() + c.status, st_bytes, stream);
   }
   // ... and, after the stream has drained, hand them out in the caller's order
   int collect_end(int loop_rc) {
@@ -271,9 +308,9 @@ struct Solve {
     for (int64_t s = 0; s < S; ++s) {
       const int32_t v = slot_view[s];
       if (v < 0) continue;
-      for (int k = 0; k < 6; ++k) p->rt[(size_t)v * 6 + k] = h_pose[(size_t)k * S + s];
-      if (p->view_status) p->view_status[v] = h_status[(size_t)s];
-      n_bad += h_status[(size_t)s] != 0;
+      for (int k = 0; k < 6; ++k) p->rt[(size_t)v * 6 + k] = r_pose[(size_t)k * S + s];
+      if (p->view_status) p->view_status[v] = r_status[(size_t)s];
+      n_bad += r_status[(size_t)s] != 0;
     }
     // totals over the ranks (multi-rank call): observations for the rms, degenerate views for a collective verdict
     double tot[2] = {(double)n_obs, (double)n_bad};
@@ -290,6 +327,7 @@ struct Solve {
     p->rms = std::sqrt(cost / tot[0]);
     p->iterations = gn ? gn->it : lm->iters;
     double* K = p->K;
+    const double* h_intr = r_intr;
     K[0] = h_intr[0]; K[1] = 0.0; K[2] = h_intr[2];
     K[3] = 0.0; K[4] = h_intr[1]; K[5] = h_intr[3];
     K[6] = 0.0; K[7] = 0.0; K[8] = 1.0;
@@ -312,6 +350,8 @@ inline int run_to_readback(Solve& s) {
   if (s.rc == 0) {
     while (!s.done()) {
       int rc = s.launch();
+      // the result copies go out behind the loop's last launch, before the host waits for its scalar
+      if (rc == 0 && s.final_launched()) rc = s.collect_begin();
       if (rc == 0) rc = s.finish();
       if (rc) { s.rc = rc; break; }
     }

@@ -19,6 +19,8 @@
 //   struct camcal_reader {            // one per running solve (RAII)
 //     int begin(const double* src, int n, int offset, void* stream);
 //     int end(double* dst_host, int n_total);
+//     double* notify(double* seq_out);  // where a kernel may write up to 7 doubles + a sequence number itself
+//     int wait(double seq, void* stream, double* dst_host, int n);     (NULL: not on this build / device)
 //   };
 //   int camcal_copy_doubles(double* dst, const double* src, int n, void* stream)
 // (begin: asynchronous copy of n doubles to position `offset` of the reader's landing
@@ -58,6 +60,9 @@ struct FisheyeGN {
   camcal_reader rd;
   double change = 1.0, cost = 0.0;
   int it = 0;
+  int fused = -1;                       // small sets: two launches per iteration (-1: not tried yet, 0: no)
+  bool have_partials = false;           // an evaluation at the current point waits in scratch
+  double seq = 0.0;                     // > 0: the scalars of this step come through the reader's notify buffer
   enum { READY, ITERATION, FINAL_COST, DONE } pending = READY;
 
   bool args_ok() const {
@@ -70,6 +75,43 @@ struct FisheyeGN {
     const int ng = camcal_glob_len(CAMCAL_FISHEYE), ns = camcal_schur_len(CAMCAL_FISHEYE);
     const bool stop = (crit_type == 1 && it >= max_count) || (crit_type == 2 && change <= eps) ||
                       (crit_type == 3 && (change <= eps || it >= max_count));
+    if (fused != 0 && !comm) {
+      // Small set: [sum + solve] and [re-estimation + the NEXT evaluation] are one launch each
+      // (camcal_reduce_solve, camcal_refine_normal_eq_partial).  The evaluation at the point the loop
+      // stops at has then been made already: its cost is the result's, no pass of its own.
+      const bool respond = Y && recompute_extrinsic;
+      if (!have_partials) {
+        const int rc = camcal_refine_normal_eq_partial(CAMCAL_FISHEYE, tiles, intr, pose, 0, 1e-10, iters,
+                                                       respond ? Y : nullptr, 0, dK, 0.0, 20, 1, scratch, stream);
+        if (rc == CAMCAL_E_UNSUPPORTED && fused < 0) fused = 0;
+        else {
+          CAMCAL_DRV_TRY(rc);
+          fused = 1;
+          have_partials = true;
+        }
+      }
+      if (fused == 1) {
+        seq = 0.0;
+        double* note = rd.notify(&seq);
+        if (!note) seq = 0.0;
+        if (stop) {
+          CAMCAL_DRV_TRY(camcal_reduce_solve(CAMCAL_FISHEYE, tiles, scratch, rec, 0, nullptr, 0.0, 0.0, nullptr, nullptr,
+                                             nullptr, nullptr, note, seq, stream));
+          if (!note) CAMCAL_DRV_TRY(rd.begin(rec + ng - 1, 1, 0, stream));
+          pending = FINAL_COST;
+          return 0;
+        }
+        const double alpha2 = 1.0 - std::pow(0.6, it + 1.0);
+        CAMCAL_DRV_TRY(camcal_reduce_solve(CAMCAL_FISHEYE, tiles, scratch, rec, 1, mask_host, 0.0, -alpha2, intr, intr, dK,
+                                           stats, note, seq, stream));
+        if (!note) CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
+        CAMCAL_DRV_TRY(camcal_refine_normal_eq_partial(CAMCAL_FISHEYE, tiles, intr, pose, recompute_extrinsic ? 20 : 0, 1e-10,
+                                                       iters, respond ? Y : nullptr, respond ? 1 : 0, dK, -alpha2, 20, 0,
+                                                       scratch, stream));
+        pending = ITERATION;
+        return 0;
+      }
+    }
     if (stop) {
       CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
                                         stream));
@@ -102,7 +144,8 @@ struct FisheyeGN {
   int finish() {
     if (pending == ITERATION) {
       double st[5];
-      CAMCAL_DRV_TRY(rd.end(st, 5));
+      if (seq > 0.0) CAMCAL_DRV_TRY(rd.wait(seq, stream, st, 5));
+      else CAMCAL_DRV_TRY(rd.end(st, 5));
       // a view whose 6x6 block is not positive definite poisons C, d with NaN; a singular reduced
       // system leaves no step (cv2 would throw from its solve / produce NaN for the caller's checkRange)
       if (st[4] == 0.0 || !std::isfinite(st[2]) || !std::isfinite(st[3])) return CAMCAL_E_NUMERIC;
@@ -112,7 +155,13 @@ struct FisheyeGN {
       return 0;
     }
     if (pending == FINAL_COST) {
-      CAMCAL_DRV_TRY(rd.end(&cost, 1));
+      if (seq > 0.0) {
+        double st[6];
+        CAMCAL_DRV_TRY(rd.wait(seq, stream, st, 6));
+        cost = st[5];
+      } else {
+        CAMCAL_DRV_TRY(rd.end(&cost, 1));
+      }
       pending = DONE;
       return std::isfinite(cost) ? 0 : CAMCAL_E_NUMERIC;
     }

@@ -19,6 +19,7 @@
 #include "../../include/camcal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -36,6 +37,16 @@ constexpr int MAX_WAVES = 4096;          // persistent waves of a reducing kerne
 constexpr int PARTIAL_STRIDE = 16384;    // row stride of the partial records in scratch: persistent kernels write <= MAX_WAVES
                                          // of them, grouped launches one per wavefront (16 lanes per view: tiles x 16)
 constexpr int MAX_NV = 96;               // widest reduced record (rig assemble, pinhole: 54 + 21 + 6 = 81)
+
+// Device functions that a fused kernel (k_refine_eval_grp, k_reduce_solve) shares with the separate stage
+// kernels.  Inlined (the default) each kernel gets its own register allocation and schedule, and the compiler
+// contracts different multiply-adds in the two contexts: the fused launch then agrees with the separate
+// stages to ~1e-13 relative, not to the bit.  -DCAMCAL_SHARED_CALL='__attribute__((noinline))' makes them
+// real calls, i.e. the SAME machine code in both (bit-identical results: checked once, tools/gpu_small_ab.py)
+// at the price of the callee-saved register traffic of two calls per launch (C2 solve 0.985 vs 0.943 ms).
+#ifndef CAMCAL_SHARED_CALL
+#define CAMCAL_SHARED_CALL __forceinline__
+#endif
 
 #define DISPATCH_MODEL_PLANAR(model, planar, L)                       \
   do {                                                                \
@@ -446,18 +457,22 @@ constexpr int GROUP = 16;
 // k_pose_predict's move applied to a pose just loaded (same arithmetic: lane_pose_predict), for the
 // refinement kernels that start from the predicted pose without a launch of their own for it
 template <int NI>
-__device__ __forceinline__ void predicted_start(const double* __restrict__ Yb, const double* __restrict__ dK, double scale,
-                                                const int32_t* __restrict__ iters, int cap, int64_t S, int64_t slot, int n,
-                                                double p[6]) {
+__device__ __forceinline__ void predicted_start_after(const double* __restrict__ Yb, const double* dK, double scale,
+                                                      bool counted, int last, int cap, int64_t S, int64_t slot, int n,
+                                                      double p[6]) {
   if (n <= 0) return;
-  if (iters) {
-    const int last = iters[slot];
-    if (last == 0 || last >= cap) return;
-  }
+  if (counted && (last == 0 || last >= cap)) return;
   double s[NI];
 #pragma unroll
   for (int a = 0; a < NI; ++a) s[a] = -scale * dK[a];
   lane_pose_predict<NI>(Yb, S, slot, s, p);
+}
+
+template <int NI>
+__device__ __forceinline__ void predicted_start(const double* __restrict__ Yb, const double* __restrict__ dK, double scale,
+                                                const int32_t* __restrict__ iters, int cap, int64_t S, int64_t slot, int n,
+                                                double p[6]) {
+  predicted_start_after<NI>(Yb, dK, scale, iters != nullptr, iters ? iters[slot] : 0, cap, S, slot, n, p);
 }
 
 template <int G>
@@ -593,6 +608,33 @@ __device__ __forceinline__ bool group_view(const camcal_tiles& t, GroupView& gv)
   return true;
 }
 
+// the Gauss-Newton loop of one view shared by the G lanes of its group (max_iter > 0); returns the steps taken
+// (A real call, not inlined: k_pose_refine_grp and k_refine_eval_grp then run the SAME machine code, so the
+// fused launch returns the separate stages' bits -- inlined into different kernels the compiler contracts
+// different multiply-adds.  Likewise group_normal_fused.)
+template <int MODEL, int G>
+__device__ CAMCAL_SHARED_CALL int group_pose_refine(const GroupView& gvr, const double* Ip, double qp[6], int max_iter, double tol) {
+  constexpr int NI = MT<MODEL>::NI;
+  const GroupView gv = gvr;                  // arguments arrive through memory: work on register copies
+  double I[NI], q[6];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) I[i] = Ip[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) q[i] = qp[i];
+  int it = 0;
+  canonical_rvec(q);
+  double ch = 1.0;
+  bool go = ch > tol;
+  while (go) {
+    const bool ok = group_pose_gn_step<MODEL, true, G>(gv.base, gv.n, I, q, ch, gv.gl);
+    if (ok) ++it;
+    go = ok && ch > tol && it < max_iter;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) qp[i] = q[i];
+  return it;
+}
+
 template <int MODEL, int G>
 __global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const double* __restrict__ intr,
                                                          double* __restrict__ pose, int max_iter, double tol,
@@ -608,14 +650,7 @@ __global__ __launch_bounds__(TPB) void k_pose_refine_grp(camcal_tiles t, const d
     load_intr<NI>(intr, I);
     load_pose(pose, S, gv.slot, q);
     if (Yb) predicted_start<NI>(Yb, dK, scale, iters, cap, S, gv.slot, gv.n, q);   // every lane of the group alike
-    canonical_rvec(q);
-    double ch = 1.0;
-    bool go = ch > tol;
-    while (go) {
-      const bool ok = group_pose_gn_step<MODEL, true, G>(gv.base, gv.n, I, q, ch, gv.gl);
-      if (ok) ++it;
-      go = ok && ch > tol && it < max_iter;
-    }
+    it = group_pose_refine<MODEL, G>(gv, I, q, max_iter, tol);
     if (gv.gl == 0) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) pose[c * S + gv.slot] = q[c];
@@ -649,26 +684,26 @@ __global__ __launch_bounds__(TPB) void k_pose_init_grp(camcal_tiles t, const dou
   }
 }
 
-// Fused normal-equation evaluation with G lanes per view: each lane accumulates its
-// share of the view's corners, the view blocks are summed over the group, the group's
-// first lane eliminates the pose; one partial record [U|b|cost|C|d] per wavefront.
+// Fused normal-equation evaluation with G lanes per view, for one view group at intrinsics I and
+// pose p: each lane accumulates its share of the view's corners, the view blocks are summed over
+// the group, the group's first lane eliminates the pose; one partial record [U|b|cost|C|d] per wavefront.
 template <int MODEL, int G>
-__global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const double* __restrict__ intr,
-                                                          const double* __restrict__ pose, double lam,
-                                                          double* __restrict__ Vb, double* __restrict__ Wb,
-                                                          double* __restrict__ gb, double* __restrict__ scratch,
-                                                          int scratch_stride, int local, double* __restrict__ Yb) {
+__device__ CAMCAL_SHARED_CALL void group_normal_fused(const GroupView& gvr, int64_t S, const double* Ip, const double* pp, double lam,
+                                                   double* __restrict__ Vb, double* __restrict__ Wb,
+                                                   double* __restrict__ gb, double* __restrict__ scratch,
+                                                   int scratch_stride, int local, double* __restrict__ Yb) {
   constexpr int NI = MT<MODEL>::NI;
   constexpr int NG = IntrAcc<MODEL>::NR;
   constexpr int NS = trisz(NI) + NI;
-  GroupView gv;
-  if (!group_view<G>(t, gv)) return;
+  const GroupView gv = gvr;                  // arguments arrive through memory: work on register copies
+  double I[NI], p[6];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) I[i] = Ip[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) p[i] = pp[i];
   const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
   const int lane = threadIdx.x & 63;
-  const int64_t S = t.n_slots;
-  double I[NI], p[6], R[9];
-  load_intr<NI>(intr, I);
-  load_pose(pose, S, gv.slot, p);
+  double R[9];
   rodrigues(p, R);
   const double tr[3] = {p[3], p[4], p[5]};
   ViewAcc<MODEL> acc;
@@ -709,23 +744,70 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
   }
 }
 
-// Evaluations A and B with G lanes per view (the pinhole LM driver's stages).
-template <int MODEL, int MODE, int G>
-__global__ __launch_bounds__(TPB) void k_intr_normal_grp(camcal_tiles t, const double* __restrict__ intr,
-                                                         const double* __restrict__ pose,
-                                                         double* __restrict__ view_cost, double* __restrict__ Vb,
-                                                         double* __restrict__ gb, double* __restrict__ scratch) {
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                          const double* __restrict__ pose, double lam,
+                                                          double* __restrict__ Vb, double* __restrict__ Wb,
+                                                          double* __restrict__ gb, double* __restrict__ scratch,
+                                                          int scratch_stride, int local, double* __restrict__ Yb) {
   constexpr int NI = MT<MODEL>::NI;
-  constexpr int NR = IntrAcc<MODEL>::NR;
-  constexpr int COST = IntrAcc<MODEL>::COST;
   GroupView gv;
   if (!group_view<G>(t, gv)) return;
-  const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
-  const int lane = threadIdx.x & 63;
   const int64_t S = t.n_slots;
-  double I[NI], p[6], R[9];
+  double I[NI], p[6];
   load_intr<NI>(intr, I);
   load_pose(pose, S, gv.slot, p);
+  group_normal_fused<MODEL, G>(gv, S, I, p, lam, Vb, Wb, gb, scratch, scratch_stride, local, Yb);
+}
+
+// Pose re-estimation and the next evaluation of a view in one launch (small sets, fisheye loop):
+// k_pose_refine_grp's body, then k_normal_fused_grp's at the refined pose, which never leaves the
+// registers.  The views need 1 ... 20 Gauss-Newton steps and the launch lasts as long as its
+// slowest view (C2: one or two views run to 18 - 20 steps in each of the first four iterations
+// while the mean is 3 - 4); evaluated in the same launch, the other views' records are done long
+// before the slowest view has converged, and a kernel boundary and the evaluation's own ramp
+// disappear from every iteration.  Same device functions, same bits as the two launches.
+// Leaves the partial records in scratch (k_reduce_solve sums them).
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_refine_eval_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                         double* __restrict__ pose, int max_iter, double tol,
+                                                         int32_t* __restrict__ iters, double* Yb, int predict,
+                                                         const double* __restrict__ dK, double scale, int cap,
+                                                         double* __restrict__ scratch, int scratch_stride,
+                                                         unsigned* counter_reset) {
+  constexpr int NI = MT<MODEL>::NI;
+  if (counter_reset && blockIdx.x == 0 && threadIdx.x == 0) *counter_reset = 0u;   // k_reduce_solve's, first launch of a solve
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int64_t S = t.n_slots;
+  double I[NI], p[6];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, gv.slot, p);
+  if (max_iter > 0) {
+    int it = 0;
+    if (gv.n >= 4) {
+      if (predict) predicted_start<NI>(Yb, dK, scale, iters, cap, S, gv.slot, gv.n, p);
+      it = group_pose_refine<MODEL, G>(gv, I, p, max_iter, tol);
+      if (gv.gl == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pose[c * S + gv.slot] = p[c];
+      }
+    }
+    if (iters && gv.gl == 0) iters[gv.slot] = it;
+  }
+  group_normal_fused<MODEL, G>(gv, S, I, p, 0.0, nullptr, nullptr, nullptr, scratch, scratch_stride, 0, Yb);
+}
+
+// Evaluations A and B with G lanes per view (the pinhole LM driver's stages).
+template <int MODEL, int MODE, int G>
+__device__ __forceinline__ void group_intr_normal(const GroupView& gv, int64_t S, const double* I, const double* p,
+                                                  double* __restrict__ view_cost, double* __restrict__ Vb,
+                                                  double* __restrict__ gb, double* __restrict__ scratch, int stride) {
+  constexpr int NR = IntrAcc<MODEL>::NR;
+  constexpr int COST = IntrAcc<MODEL>::COST;
+  const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  double R[9];
   rodrigues(p, R);
   const double tr[3] = {p[3], p[4], p[5]};
   IntrAcc<MODEL> acc;
@@ -758,11 +840,26 @@ __global__ __launch_bounds__(TPB) void k_intr_normal_grp(camcal_tiles t, const d
     }
   }
   if (MODE > 0) {
-    wave_reduce_store<NR>(acc.v, scratch, wave);
+    wave_scatter_store<NR>(acc.v, lane, scratch + wave, stride);
   } else {
     const double s = wave_sum(acc.v[COST]);
-    if (lane == 0) scratch[(size_t)COST * PARTIAL_STRIDE + wave] = s;
+    if (lane == 0) scratch[(size_t)COST * stride + wave] = s;
   }
+}
+
+template <int MODEL, int MODE, int G>
+__global__ __launch_bounds__(TPB) void k_intr_normal_grp(camcal_tiles t, const double* __restrict__ intr,
+                                                         const double* __restrict__ pose,
+                                                         double* __restrict__ view_cost, double* __restrict__ Vb,
+                                                         double* __restrict__ gb, double* __restrict__ scratch) {
+  constexpr int NI = MT<MODEL>::NI;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int64_t S = t.n_slots;
+  double I[NI], p[6];
+  load_intr<NI>(intr, I);
+  load_pose(pose, S, gv.slot, p);
+  group_intr_normal<MODEL, MODE, G>(gv, S, I, p, view_cost, Vb, gb, scratch, PARTIAL_STRIDE);
 }
 
 template <int MODEL, int G>
@@ -912,13 +1009,20 @@ __device__ __forceinline__ double lane_bcast(double x, int src) {
                           __builtin_amdgcn_readlane(__double2loint(x), src));
 }
 
-__global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __restrict__ glob,
-                                                      const double* __restrict__ schur, unsigned mask, double lam,
-                                                      double scale, const double* intr_in, double* intr_out,
-                                                      double* __restrict__ dK, double* __restrict__ stats) {
+// LDS traffic between the lanes of ONE wavefront (its ds instructions execute in order): only the
+// compiler has to be kept from moving accesses across this point
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// executed by one whole wavefront; s_st / s_in / s_out: 9 doubles of LDS each, private to this wavefront;
+// glob, schur, intr_in / intr_out (may be the same), dK, stats: global or LDS
+__device__ CAMCAL_SHARED_CALL void solve_reduced_wave(int NI, const double* glob, const double* schur, unsigned mask,
+                                                   double lam, double scale, const double* intr_in, double* intr_out,
+                                                   double* dK, double* stats, double* s_st, double* s_in, double* s_out) {
   constexpr int MAXN = 9;
-  __shared__ double s_st[MAXN], s_in[MAXN], s_out[MAXN];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int NU = NI * (NI + 1) / 2;
   mask &= (1u << NI) - 1u;
   const int nf = __popc(mask);
@@ -1008,13 +1112,13 @@ __global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __re
     const double in = intr_in[lane];
     s_st[lane] = 0.0; s_in[lane] = in; s_out[lane] = in;
   }
-  __syncthreads();
+  wave_lds_sync();
   if (active) {
-    const double d = xi * sc, in = intr_in[a], st = scale * d;
+    const double d = xi * sc, in = s_in[a], st = scale * d;
     s_st[a] = st; s_out[a] = in + st;
     dK[a] = d;
   }
-  __syncthreads();
+  wave_lds_sync();
   if (lane < NI) {
     intr_out[lane] = s_out[lane];
     if (!((mask >> lane) & 1u)) dK[lane] = 0.0;
@@ -1028,6 +1132,74 @@ __global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __re
       if (p < 4) { s2 += st * st; s3 += out * out; }
     }
     stats[0] = s0; stats[1] = s1; stats[2] = s2; stats[3] = s3; stats[4] = okf;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_solve_reduced(int NI, const double* __restrict__ glob,
+                                                      const double* __restrict__ schur, unsigned mask, double lam,
+                                                      double scale, const double* intr_in, double* intr_out,
+                                                      double* __restrict__ dK, double* __restrict__ stats) {
+  __shared__ double s_st[9], s_in[9], s_out[9];
+  solve_reduced_wave(NI, glob, schur, mask, lam, scale, intr_in, intr_out, dK, stats, s_st, s_in, s_out);
+}
+
+// k_finalize_strided's sum of one row by the calling workgroup (every thread calls); thread 0 returns the sum
+__device__ __forceinline__ double block_row_sum(const double* __restrict__ row, int n, double* sh) {
+  const double v = strided_partial_sum(row, n);
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int st = TPB / 2; st >= 1; st >>= 1) {
+    if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+    __syncthreads();
+  }
+  const double r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// Second stage of an evaluation and the reduced solve in one launch: workgroup r sums row r of the
+// partial records (k_finalize_strided); the workgroup that finishes last (a counter in device memory,
+// left at zero again) expands the sums into the record [U|b|cost|C|d] (k_expand) and, with do_solve,
+// solves the reduced system (k_solve_reduced).  Nobody waits for anybody: no workgroup spins.
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_reduce_solve(const double* __restrict__ scratch, int n_part, double* red,
+                                                      unsigned* counter, double* __restrict__ rec, int do_solve,
+                                                      unsigned mask, double lam, double scale, const double* intr_in,
+                                                      double* intr_out, double* dK, double* stats, double* notify,
+                                                      double seq) {
+  constexpr int NI = MT<MODEL>::NI, NR = IntrAcc<MODEL>::NR, NV = IntrAcc<MODEL>::NV, NS = trisz(NI) + NI;
+  __shared__ double s_sh[TPB], s_red[NR + NS], s_rec[NV + NS], s_st[9], s_in[9], s_out[9], s_stats[5];
+  __shared__ unsigned s_last;
+  const double v = block_row_sum(scratch + (size_t)blockIdx.x * n_part, n_part, s_sh);
+  if (threadIdx.x == 0) {
+    red[blockIdx.x] = v;
+    __threadfence();
+    s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < NR + NS) s_red[threadIdx.x] = __hip_atomic_load(&red[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *counter = 0u;                                     // for the next launch on this scratch
+    IntrAcc<MODEL>::expand(s_red, s_rec);
+    for (int i = 0; i < NS; ++i) s_rec[NV + i] = s_red[NR + i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV + NS) rec[threadIdx.x] = s_rec[threadIdx.x];
+  if (threadIdx.x >= 64) return;
+  if (do_solve) {
+    solve_reduced_wave(NI, s_rec, s_rec + NV, mask, lam, scale, intr_in, intr_out, dK, s_stats, s_st, s_in, s_out);
+    wave_lds_sync();
+    if (threadIdx.x < 5) stats[threadIdx.x] = s_stats[threadIdx.x];
+  }
+  // the scalars the host decides on, straight into its pinned memory: [stats (5) | cost | - | seq], seq last
+  if (notify && threadIdx.x == 0) {
+    for (int i = 0; i < 5; ++i) notify[i] = do_solve ? s_stats[i] : 0.0;
+    notify[5] = s_rec[NV - 1];
+    __threadfence_system();
+    __hip_atomic_store(&notify[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1395,6 +1567,55 @@ int camcal_pose_predict_refine(int model, const camcal_tiles* tiles, const doubl
                                int32_t* iters, void* stream) {
   if (!Y || !dK) return CAMCAL_E_BADARG;
   return pose_refine_impl(model, tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap, stream);
+}
+
+// where k_refine_eval_grp / k_reduce_solve keep their reduced values and their counter: behind the
+// partial records, as camcal_normal_eq_fused does for a grouped set
+static inline double* small_set_red(const camcal_tiles* tiles, int G, int rows, double* scratch) {
+  return scratch + (size_t)rows * ((size_t)tiles->n_tiles * G);
+}
+static inline unsigned* small_set_counter(const camcal_tiles* tiles, int G, int rows, double* scratch) {
+  return (unsigned*)(small_set_red(tiles, G, rows, scratch) + 2 * MAX_NV - 8);
+}
+
+int camcal_refine_normal_eq_partial(int model, const camcal_tiles* tiles, const double* intr, double* pose, int max_iter,
+                                    double tol, int32_t* iters, double* Y, int predict, const double* dK, double scale,
+                                    int cap, int first, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !scratch || max_iter < 0) return CAMCAL_E_BADARG;
+  if (predict && (!Y || !dK)) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int G = group_lanes(tiles);
+  if (G <= 1 || model != CAMCAL_FISHEYE) return CAMCAL_E_UNSUPPORTED;   // large sets: the stages on their own
+  const int np = tiles->n_tiles * G;
+  const int rows = IntrAcc<FISHEYE>::NR + camcal_schur_len(CAMCAL_FISHEYE);
+  unsigned* counter = first ? small_set_counter(tiles, G, rows, scratch) : nullptr;
+  const dim3 gg(grid_groups(tiles, G)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 64) hipLaunchKernelGGL((k_refine_eval_grp<FISHEYE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, predict, dK, scale, cap, scratch, np, counter);
+  else hipLaunchKernelGGL((k_refine_eval_grp<FISHEYE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, predict, dK, scale, cap, scratch, np, counter);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, double* rec, int do_solve,
+                        const uint8_t* mask_host, double lam, double scale, const double* intr_in, double* intr_out,
+                        double* dK, double* stats, double* notify, double seq, void* stream) {
+  if (!tiles_ok(tiles) || !scratch || !rec) return CAMCAL_E_BADARG;
+  if (do_solve && (!mask_host || !intr_in || !intr_out || !dK || !stats)) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int G = group_lanes(tiles);
+  if (G <= 1 || model != CAMCAL_FISHEYE) return CAMCAL_E_UNSUPPORTED;
+  const int np = tiles->n_tiles * G;
+  const int rows = IntrAcc<FISHEYE>::NR + camcal_schur_len(CAMCAL_FISHEYE);
+  unsigned mask = 0;
+  if (do_solve)
+    for (int a = 0; a < 8; ++a)
+      if (mask_host[a]) mask |= 1u << a;
+  hipLaunchKernelGGL(k_reduce_solve<FISHEYE>, dim3(rows), dim3(TPB), 0, (hipStream_t)stream, scratch, np,
+                     small_set_red(tiles, G, rows, scratch), small_set_counter(tiles, G, rows, scratch), rec, do_solve, mask,
+                     lam, scale, intr_in, intr_out, dK, stats, notify, seq);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int camcal_intr_normal(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
@@ -1888,9 +2109,12 @@ namespace {
 constexpr int READ_CAP = 64;
 struct ReadBack {
   double* pinned = nullptr;
+  double* mapped = nullptr;        // the same buffer as the device sees it (NULL: not mapped)
+  double seq = 0.0;                // last sequence number handed out for pinned[NOTIFY_SEQ]
   hipEvent_t ev = nullptr;
   int dev = -1;
 };
+constexpr int NOTIFY_SEQ = 7;
 std::mutex g_rb_mu;
 std::vector<ReadBack*> g_rb_free;
 
@@ -1921,7 +2145,17 @@ struct camcal_reader {
     }
     ReadBack* n = new ReadBack();
     n->dev = dev;
-    hipError_t e = hipHostMalloc((void**)&n->pinned, READ_CAP * sizeof(double), hipHostMallocPortable);
+    // coherent + mapped: kernels may write the landing buffer themselves (notify / wait below)
+    hipError_t e = hipHostMalloc((void**)&n->pinned, READ_CAP * sizeof(double),
+                                 hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, n->pinned, 0) == hipSuccess) n->mapped = (double*)d;
+      else (void)hipGetLastError();
+    } else {
+      (void)hipGetLastError();
+      e = hipHostMalloc((void**)&n->pinned, READ_CAP * sizeof(double), hipHostMallocPortable);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&n->ev, hipEventDisableTiming);
     if (e != hipSuccess) {
       if (n->pinned) (void)hipHostFree(n->pinned);
@@ -1946,6 +2180,36 @@ struct camcal_reader {
     HIP_TRY(hipEventSynchronize(rb->ev));
     pending = false;
     for (int i = 0; i < n_total; ++i) dst_host[i] = rb->pinned[i];
+    return 0;
+  }
+  // A kernel writes the first doubles of the landing buffer itself and the sequence number last
+  // (camcal_reduce_solve): notify() = where (device view; NULL: this build / device cannot, use begin / end)
+  // and which number; wait() = spin on the number, looking at the stream now and then so that a launch that
+  // died does not leave the host spinning.
+  double* notify(double* seq_out) {
+    if (acquire() != 0 || !rb->mapped) return nullptr;
+    rb->seq += 1.0;
+    *seq_out = rb->seq;
+    return rb->mapped;
+  }
+  int wait(double seq, void* stream, double* dst_host, int n) {
+    if (!rb || !rb->mapped || n <= 0 || n > NOTIFY_SEQ || !dst_host) return CAMCAL_E_BADARG;
+    volatile double* flag = rb->pinned + NOTIFY_SEQ;
+    for (unsigned spins = 1;; ++spins) {
+      if (*flag == seq) break;
+      if ((spins & 1023u) == 0) {
+        const hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) {                       // everything queued has run: the number is there or never will be
+          if (*flag == seq) break;
+          return CAMCAL_E_NUMERIC;
+        }
+        if (e != hipErrorNotReady) return (int)e;
+        (void)hipGetLastError();
+      }
+      __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    for (int i = 0; i < n; ++i) dst_host[i] = rb->pinned[i];
     return 0;
   }
 };
@@ -2027,6 +2291,50 @@ int camcal_download(void* dst_host, const void* src_dev, size_t bytes, void* str
 int camcal_stream_sync(void* stream) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return 0;
+}
+// Page-locked staging for camcal_calibrate's one upload and one download: a free list, grown on demand and
+// kept until the process ends (a production-sized call must not pay hipHostMalloc).
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+std::mutex g_pin_mu;
+std::vector<PinBuf> g_pin_free, g_pin_used;
+void* camcal_pinned_take(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  int best = -1;
+  for (size_t i = 0; i < g_pin_free.size(); ++i)
+    if (g_pin_free[i].cap >= bytes && (best < 0 || g_pin_free[i].cap < g_pin_free[(size_t)best].cap)) best = (int)i;
+  PinBuf b;
+  if (best >= 0) {
+    b = g_pin_free[(size_t)best];
+    g_pin_free.erase(g_pin_free.begin() + best);
+  } else {
+    const size_t cap = ((bytes + (bytes >> 2)) + 65535) & ~(size_t)65535;
+    if (hipHostMalloc(&b.p, cap, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    b.cap = cap;
+  }
+  g_pin_used.push_back(b);
+  return b.p;
+}
+void camcal_pinned_give(void* p) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  for (size_t i = 0; i < g_pin_used.size(); ++i)
+    if (g_pin_used[i].p == p) {
+      g_pin_free.push_back(g_pin_used[i]);
+      g_pin_used.erase(g_pin_used.begin() + (long)i);
+      break;
+    }
+  while (g_pin_free.size() > 16) {                 // keep the pool bounded: drop the smallest
+    size_t k = 0;
+    for (size_t i = 1; i < g_pin_free.size(); ++i)
+      if (g_pin_free[i].cap < g_pin_free[k].cap) k = i;
+    (void)hipHostFree(g_pin_free[k].p);
+    g_pin_free.erase(g_pin_free.begin() + (long)k);
+  }
 }
 int camcal_get_device(int* dev) {
   HIP_TRY(hipGetDevice(dev));

@@ -408,6 +408,23 @@ class Engine:
         self._call("camcal_pose_predict", self.model, self._tp(), self.Y.data_ptr(), self.dK.data_ptr(),
                    float(scale), self.iters.data_ptr(), 20, self.pose[pose_idx].data_ptr(), self._stream())
 
+    def refine_normal_eq_partial(self, intr_idx, pose_idx, max_iter=20, predict=False, scale=0.0, first=False,
+                                 respond=True):
+        """Small sets, fisheye: the re-estimation (from the predicted poses with ``predict``; skipped with
+        ``max_iter`` 0) and the evaluation at the refined poses in one launch; the evaluation stays in
+        ``self.scratch`` as partial records for ``reduce_solve`` (camcal_refine_normal_eq_partial)."""
+        self._call("camcal_refine_normal_eq_partial", self.model, self._tp(), self.intr[intr_idx].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), int(max_iter), 1e-10, self.iters.data_ptr(),
+                   self.Y.data_ptr() if respond else None, 1 if predict else 0, self.dK.data_ptr(), float(scale), 20,
+                   1 if first else 0, self.scratch.data_ptr(), self._stream())
+
+    def reduce_solve(self, mask, lam, scale, intr_in, intr_out, solve=True):
+        """Sum of those partial records into ``self.rec`` and, with ``solve``, the reduced solve on it in the
+        same launch (camcal_reduce_solve)."""
+        self._call("camcal_reduce_solve", self.model, self._tp(), self.scratch.data_ptr(), self.rec.data_ptr(),
+                   1 if solve else 0, self._mask_bytes(mask), float(lam), float(scale), self.intr[intr_in].data_ptr(),
+                   self.intr[intr_out].data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(), None, 0.0, self._stream())
+
     def reproj_err(self, intr_idx, pose_idx, f32_round=True):
         """Per-view ||proj - corners||_2 / n (caller's view order) and their mean."""
         out = torch.zeros(2, dtype=torch.float64, device=self.device)

@@ -237,6 +237,36 @@ int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const do
                                   const double* pose, double lam, double* glob, double* schur,
                                   void* stream);
 
+/* ---- Small view sets (several lanes per view: planar, <= 28 672 views -- the reference's own calls hold
+ * 20 ... 500), fisheye loop: two stages that fold the five launches of an iteration into two.  A
+ * production-sized iteration is a chain of ~5 ... 60 us kernels whose length is set by the one or two views
+ * that need 18 - 20 Gauss-Newton steps; every launch boundary and every separate small kernel on that
+ * chain is wall clock.  CAMCAL_E_UNSUPPORTED for other sets and for the pinhole model (callers then use
+ * the stages above; camcal_fisheye_gn does).  NO COUNTERPART IN THE REFERENCE (cv2 runs the loop inside
+ * cv::fisheye::calibrate, camera_calib.py:74-77).
+ *
+ * camcal_refine_normal_eq_partial: camcal_pose_predict_refine (predict != 0; needs Y, dK) or
+ * camcal_pose_refine (predict == 0), skipped altogether with max_iter == 0, followed IN THE SAME LAUNCH
+ * by the evaluation of camcal_normal_eq_fused_response (Y != NULL: the new response replaces the one
+ * just used) or camcal_normal_eq_fused (Y == NULL, lam = 0, no stored blocks) at the refined poses --
+ * a view's record is complete while slower views still iterate.  The evaluation is left as partial
+ * records in scratch for camcal_reduce_solve.  first != 0: first launch of a solve on this scratch
+ * (clears camcal_reduce_solve's counter).  Same device code as the separate stages: same bits. */
+int camcal_refine_normal_eq_partial(int model, const camcal_tiles* tiles, const double* intr, double* pose,
+                                    int max_iter, double tol, int32_t* iters, double* Y, int predict,
+                                    const double* dK, double scale, int cap, int first, double* scratch,
+                                    void* stream);
+/* camcal_reduce_solve: the second stage of that evaluation (fixed-order sums, rec = [U|b|cost|C|d] as
+ * camcal_normal_eq_fused leaves glob | schur) and, with do_solve, camcal_solve_reduced on it, in one
+ * launch: the workgroup that finishes its row last (a counter in scratch) expands and solves.
+ * notify (or NULL): the device-visible address of 8 doubles of pinned, coherent host memory
+ * (hipHostMalloc + hipHostGetDevicePointer).  The launch itself writes [stats (5) | cost | - | seq]
+ * there, seq last, so the host can act on the scalars as soon as they exist -- no copy on the stream
+ * between this launch and the next, which is what a production-sized iteration would otherwise wait for. */
+int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, double* rec, int do_solve,
+                        const uint8_t* mask_host, double lam, double scale, const double* intr_in,
+                        double* intr_out, double* dK, double* stats, double* notify, double seq, void* stream);
+
 /* ---- Multi-GPU: views shard across ranks (one process per GPU); the only data exchanged are
  * the small global records, summed over the ranks between the stages of a solve.  The
  * reference has no counterpart (single process).  A camcal_comm tells the solver loops how
@@ -287,7 +317,11 @@ int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void*
  * every re-estimation starts from the first-order predicted pose (camcal_pose_predict)
  * instead of the previous one -- same results to the refinement's tolerance, about a third
  * fewer Gauss-Newton steps per view.
- * cost_out_host = sum of squared residuals at the result. */
+ * cost_out_host = sum of squared residuals at the result.
+ * Single-rank calls on small sets run each iteration as camcal_reduce_solve +
+ * camcal_refine_normal_eq_partial (two launches instead of five; the cost at the result comes from
+ * the last evaluation instead of a pass of its own, so it can differ from the staged loop's in the
+ * last bits of the sum; K, D, poses are identical); rec then holds the evaluation AT the result. */
 int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
                       int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec,
                       double* dK, double* stats, int32_t* iters, double* Y, double* scratch,

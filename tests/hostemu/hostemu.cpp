@@ -354,7 +354,7 @@ int camcal_version(void) { return -100; }   // negative: emulator
 int camcal_n_intr(int model) { return model == 0 ? 9 : model == 1 ? 8 : CAMCAL_E_BADMODEL; }
 int camcal_glob_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni + 1; }
 int camcal_schur_len(int model) { const int ni = camcal_n_intr(model); return ni < 0 ? ni : ni * (ni + 1) / 2 + ni; }
-int64_t camcal_scratch_len(int, int) { return 64; }
+int64_t camcal_scratch_len(int, int) { return 256; }   // room for one finished record (camcal_refine_normal_eq_partial)
 
 int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, int64_t* n_slots,
                   int64_t* total_floats, int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off) {
@@ -498,6 +498,42 @@ int camcal_pose_predict_refine(int model, const camcal_tiles* t, const double* i
   if (!Y || !dK) return CAMCAL_E_BADARG;
   const int rc = camcal_pose_predict(model, t, Y, dK, scale, iters, cap, pose, s);
   return rc ? rc : camcal_pose_refine(model, t, intr, pose, max_iter, tol, iters, s);
+}
+// the two-launch iteration of small sets: same arithmetic as the stages; the "partial records" of the
+// emulator are the finished record, kept in scratch between the two calls
+int camcal_refine_normal_eq_partial(int model, const camcal_tiles* t, const double* intr, double* pose, int max_iter,
+                                    double tol, int32_t* iters, double* Y, int predict, const double* dK, double scale,
+                                    int cap, int, double* scratch, void* s) {
+  if (!t || !intr || !pose || !scratch || max_iter < 0 || (predict && (!Y || !dK))) return CAMCAL_E_BADARG;
+  if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
+  if (lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view) <= 1 || model != 1) return CAMCAL_E_UNSUPPORTED;
+  if (max_iter > 0) {
+    const int rc = predict ? camcal_pose_predict_refine(model, t, intr, Y, dK, scale, cap, pose, max_iter, tol, iters, s)
+                           : camcal_pose_refine(model, t, intr, pose, max_iter, tol, iters, s);
+    if (rc) return rc;
+  }
+  const int ng = camcal_glob_len(model);
+  if (Y) return camcal_normal_eq_fused_response(model, t, intr, pose, Y, scratch, scratch + ng, nullptr, s);
+  return camcal_normal_eq_fused(model, t, intr, pose, 0.0, nullptr, nullptr, nullptr, scratch, scratch + ng, nullptr, s);
+}
+int camcal_reduce_solve(int model, const camcal_tiles* t, double* scratch, double* rec, int do_solve, const uint8_t* mask_host,
+                        double lam, double scale, const double* intr_in, double* intr_out, double* dK, double* stats,
+                        double* notify, double seq, void* s) {
+  if (!t || !scratch || !rec || (do_solve && (!mask_host || !intr_in || !intr_out || !dK || !stats))) return CAMCAL_E_BADARG;
+  if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
+  if (lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view) <= 1 || model != 1) return CAMCAL_E_UNSUPPORTED;
+  const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
+  for (int i = 0; i < ng + ns; ++i) rec[i] = scratch[i];
+  if (do_solve) {
+    const int rc = camcal_solve_reduced(model, rec, rec + ng, mask_host, lam, scale, intr_in, intr_out, dK, stats, s);
+    if (rc) return rc;
+  }
+  if (notify) {
+    for (int i = 0; i < 5; ++i) notify[i] = do_solve ? stats[i] : 0.0;
+    notify[5] = rec[ng - 1];
+    notify[7] = seq;
+  }
+  return 0;
 }
 int camcal_normal_eq_fused_static(int model, const camcal_tiles* t, const double* intr, const double* pose, double lam,
                                   double* glob, double* schur_out, void* s) {
@@ -705,6 +741,7 @@ int camcal_peak_probe(int, void*, int64_t, int, void*, double* r) { if (r) *r = 
 }  // extern "C"
 
 // Host-side solver loops: the same sequencing code as the HIP library, over this emulator's stages.
+#include <cstdlib>
 #include <cstring>
 namespace {
 struct camcal_reader {
@@ -717,6 +754,13 @@ struct camcal_reader {
   int end(double* dst_host, int n_total) {
     if (n_total <= 0 || n_total > 64 || !dst_host) return CAMCAL_E_BADARG;
     std::memcpy(dst_host, landing, (size_t)n_total * sizeof(double));
+    return 0;
+  }
+  double seq = 0.0;
+  double* notify(double* seq_out) { seq += 1.0; *seq_out = seq; return landing; }
+  int wait(double want, void*, double* dst_host, int n) {
+    if (landing[7] != want || n <= 0 || n > 7) return CAMCAL_E_BADARG;
+    std::memcpy(dst_host, landing, (size_t)n * sizeof(double));
     return 0;
   }
 };
@@ -787,6 +831,8 @@ int camcal_join_streams(void*, int, void**) { return 0; }
 int camcal_upload(void* dst, const void* src_host, size_t bytes, void*) { std::memcpy(dst, src_host, bytes); return 0; }
 int camcal_download(void* dst_host, const void* src, size_t bytes, void*) { std::memcpy(dst_host, src, bytes); return 0; }
 int camcal_stream_sync(void*) { return 0; }
+void* camcal_pinned_take(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void camcal_pinned_give(void* p) { std::free(p); }
 int camcal_get_device(int* dev) { *dev = 0; return 0; }
 int camcal_set_device(int) { return 0; }
 }  // namespace

@@ -531,6 +531,64 @@ def case_pose_response_and_predicted_warm_start():
 ALL.append(case_pose_response_and_predicted_warm_start)
 
 
+def case_two_launch_iteration_of_small_sets():
+    """camcal_refine_normal_eq_partial + camcal_reduce_solve (what camcal_fisheye_gn runs on small sets: two
+    launches per iteration) against the five separate stages: the same record, intrinsic step, poses and step
+    counts, 16 and 64 lanes per view.  Same device functions, but inlined into different kernels (different
+    multiply-add contraction): equal to 1e-12, not to the bit (the shared-call build, camcal_kernels.hip
+    CAMCAL_SHARED_CALL, is bit-identical); one lane per view is refused (the stages run then)."""
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    P = synth.config("C3", n_views=150)
+    g = P.intr_guess()
+    mask = np.ones(8, dtype=bool)
+
+    def close(x, y, tol=1e-12):
+        return np.abs(x - y).max() <= tol * max(np.abs(x).max(), 1e-300)
+    for lpv in (16, 64):
+        A = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
+        B = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
+        for E in (A, B):
+            E.set_intr(0, g)
+            E.pose_init(0, 0)
+            E.pose_refine(0, 0, 20, 1e-10)
+        A.normal_eq_response(0, 0)                       # stages: evaluation | solve | predict + refine | evaluation
+        B.refine_normal_eq_partial(0, 0, max_iter=0, first=True)
+        for k in range(3):
+            a2 = 1.0 - 0.6 ** (k + 1)
+            A.solve_reduced(0, mask, 0.0, -a2, 0, 0)
+            B.reduce_solve(mask, 0.0, -a2, 0, 0)
+            assert close(A.rec.cpu().numpy()[:89], B.rec.cpu().numpy()[:89]), (lpv, k)
+            assert close(A.dK.cpu().numpy()[:8], B.dK.cpu().numpy()[:8], 1e-9), (lpv, k)       # a solve amplifies by cond
+            assert close(A.stats.cpu().numpy()[:5], B.stats.cpu().numpy()[:5], 1e-9), (lpv, k)
+            assert close(A.get_intr(0), B.get_intr(0)), (lpv, k)
+            A._call("camcal_pose_predict_refine", A.model, A._tp(), A.intr[0].data_ptr(), A.Y.data_ptr(), A.dK.data_ptr(),
+                    -a2, 20, A.pose[0].data_ptr(), 20, 1e-10, A.iters.data_ptr(), A._stream())
+            A.normal_eq_response(0, 0)
+            B.refine_normal_eq_partial(0, 0, max_iter=20, predict=True, scale=-a2)
+            pa, pb = A.get_poses(0), B.get_poses(0)
+            assert np.abs(pa - pb).max() < 1e-9 * max(1.0, np.abs(pa).max()), (lpv, k)
+            ia, ib = A.iters.cpu().numpy(), B.iters.cpu().numpy()
+            assert (ia != ib).mean() <= 0.02 and np.abs(ia - ib).max() <= 1      # a view at the stop rule's edge may take one step more
+            ya, yb = A.Y.cpu().numpy(), B.Y.cpu().numpy()
+            assert np.abs(ya - yb).max() <= 1e-7 * np.abs(ya).max()
+        B.reduce_solve(mask, 0.0, 0.0, 0, 0, solve=False)
+        assert close(A.rec.cpu().numpy()[:89], B.rec.cpu().numpy()[:89], 1e-11)
+        del A, B
+    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=1)
+    E.set_intr(0, g)
+    E.pose_init(0, 0)
+    try:
+        E.refine_normal_eq_partial(0, 0, max_iter=0, first=True)
+        raise AssertionError("one lane per view must be refused")
+    except _lib.CamcalStatus as exc:
+        assert exc.code == _lib.E_UNSUPPORTED
+
+
+ALL.append(case_two_launch_iteration_of_small_sets)
+
+
 def case_one_call_entry_and_calibrate_many():
     """camcal_calibrate (what the plain drop-in call runs) against the stage-by-stage Engine path (chosen by
     passing _info), bit for bit; camcal_calibrate_many on the reference's four-camera loop (cali_in:

@@ -245,8 +245,15 @@ def test_library_sequenced_loops_equal_the_python_loops_on_gpu(dev):
             res.append((r, info))
         (a, ia), (b, ib) = res
         assert ia["log"] is None and len(ib["log"]) == ib["iters"] == ia["iters"]
-        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-        assert np.array_equal(np.hstack(a[3]), np.hstack(b[3]))
+        if P.model == "pinhole":          # the same stage launches in both: the same bits
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+            assert np.array_equal(np.hstack(a[3]), np.hstack(b[3]))
+        else:
+            # small fisheye sets: the library folds an iteration's five launches into two (same device functions
+            # inlined into other kernels: other multiply-add contraction), the Python loop keeps the five
+            assert abs(a[0] - b[0]) <= 1e-12 * b[0] and np.allclose(a[1], b[1], rtol=1e-11, atol=0)
+            assert np.allclose(a[2], b[2], rtol=1e-8, atol=1e-14)
+            assert np.allclose(np.hstack(a[3]), np.hstack(b[3]), rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("nv", [1, 63, 65, 2048, 2049, 28672, 28673])
@@ -490,8 +497,13 @@ def test_multi_rank_loop_through_the_library_communicators(dev):
                 comm = Comm(enabled=True, backend=backend)
                 r = fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=CRIT, _comm=comm)
                 assert comm.kind == backend
-                assert r[0] == ref[0] and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
-                assert np.array_equal(np.hstack(r[3]), np.hstack(ref[3]))
+                if P.model == "pinhole":       # same stage launches with and without a communicator: same bits
+                    assert r[0] == ref[0] and np.array_equal(r[1], ref[1]) and np.array_equal(r[2], ref[2])
+                    assert np.array_equal(np.hstack(r[3]), np.hstack(ref[3]))
+                else:                          # the single-rank fisheye loop of a small set uses the two-launch iteration
+                    assert abs(r[0] - ref[0]) <= 1e-12 * ref[0] and np.allclose(r[1], ref[1], rtol=1e-11, atol=0)
+                    assert np.allclose(r[2], ref[2], rtol=1e-8, atol=1e-14)
+                    assert np.allclose(np.hstack(r[3]), np.hstack(ref[3]), rtol=0, atol=1e-9)
         # the collective itself: in place, on the stream, value-preserving for one rank
         lib = _lib.load()
         E = Engine(1, P.view_ptr, P.obj, P.img, dev) if P.model == "fisheye" else Engine(0, P.view_ptr, P.obj, P.img, dev)
