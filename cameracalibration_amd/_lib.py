@@ -88,6 +88,11 @@ _SIGNATURES = {
     "camcal_refine_normal_eq_partial": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_double, _P, _P, C.c_int, _P, C.c_double,
                                                   C.c_int, C.c_int, _P, _P]),
     "camcal_reduce_solve": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, _P, C.c_double, C.c_double, _P, _P, _P, _P, _P, C.c_double, _P]),
+    "camcal_small_set_begin": (C.c_int, [C.c_int, _P, _P, _P]),
+    "camcal_cross_schur_solve": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_double, _P, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P]),
+    "camcal_schur_solve": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_double, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P]),
+    "camcal_backsub_intr_normal": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                             C.c_double, _P, _P]),
     "camcal_comm_size": (C.c_int, [_P]),
     "camcal_comm_allreduce": (C.c_int, [_P, _P, C.c_int64, _P]),
     "camcal_normal_eq_fused_response": (C.c_int, [_I, _TP, _P, _P, _P, _P, _P, _P, _P]),

@@ -74,7 +74,7 @@ inline Carve carve(int model, int64_t n_views, int64_t n_obs, int32_t T, int64_t
   c.tables_bytes = o;
   o = up8(o);
   c.img = o; o += (size_t)n_obs * 8;
-  c.obj = o; o = up8(o + (size_t)n_obs * 12);
+  c.obj = o; o = (o + (size_t)n_obs * 12 + 15) & ~(size_t)15;
   c.intr0 = o; o += 16 * sizeof(double);
   c.up_bytes = o;
   c.pose0 = o; o += 6 * (size_t)S * sizeof(double);

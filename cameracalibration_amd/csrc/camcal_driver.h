@@ -189,6 +189,10 @@ struct PinholeLM {
   // state
   camcal_reader rd;
   int cur = 0;                         // which physical buffer holds the current point
+  int fused = -1;                      // small sets: four launches per step (-1: not tried yet, 0: no)
+  double* glob_cur = nullptr;          // fused: [U|b|cost] of the current point (rec or glob_trial, swapped on accept)
+  double* glob_tri = nullptr;
+  double seq = 0.0;                    // > 0: the step's scalars come through the reader's notify buffer
   int lam_lg10 = -3, iters = 0;
   double err = 0.0, prev_err = 0.0;
   bool fresh = true;
@@ -210,6 +214,15 @@ struct PinholeLM {
     if (pending == START) {
       max_iter = max_iter < 1 ? 1 : (max_iter > 1000 ? 1000 : max_iter);
       if (!(eps > 2.220446049250313e-16)) eps = 2.220446049250313e-16;
+      if (!comm && fused < 0) {          // small set, one rank: the folded step (camcal_cross_schur_solve ...)
+        const int rc = camcal_small_set_begin(M, tiles, scratch, stream);
+        if (rc != 0 && rc != CAMCAL_E_UNSUPPORTED) return rc;
+        fused = rc == 0 ? 1 : 0;
+      } else if (fused < 0) {
+        fused = 0;
+      }
+      glob_cur = rec;
+      glob_tri = glob_trial;
       CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[cur], pose2[cur], 1, glob, nullptr, V2[cur], g2[cur], scratch,
                                         stream));
       CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob, ng, stream));
@@ -220,6 +233,24 @@ struct PinholeLM {
     if (pending != READY) return CAMCAL_E_BADARG;
     const int tri = 1 - cur;
     const double lam = std::pow(10.0, (double)lam_lg10);
+    if (fused == 1) {
+      if (fresh) CAMCAL_DRV_TRY(camcal_cross_schur_solve(M, tiles, intr2[cur], pose2[cur], V2[cur], g2[cur], lam, W, glob_cur,
+                                                         schur, mask_host, -1.0, intr2[tri], dK, stats, scratch, stream));
+      else CAMCAL_DRV_TRY(camcal_schur_solve(M, tiles, V2[cur], W, g2[cur], lam, glob_cur, schur, mask_host, -1.0, intr2[cur],
+                                             intr2[tri], dK, stats, scratch, stream));
+      seq = 0.0;
+      double* note = rd.notify(&seq);
+      if (!note) seq = 0.0;
+      CAMCAL_DRV_TRY(camcal_backsub_intr_normal(M, tiles, V2[cur], W, g2[cur], lam, dK, pose2[cur], pose2[tri], intr2[tri],
+                                                glob_tri, V2[tri], g2[tri], norms, stats, note, seq, scratch, stream));
+      if (!note) {
+        CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
+        CAMCAL_DRV_TRY(rd.begin(norms, 2, 5, stream));
+        CAMCAL_DRV_TRY(rd.begin(glob_tri + ng - 1, 1, 7, stream));
+      }
+      pending = TRIAL;
+      return 0;
+    }
     // evaluation B at the current point for a fresh step, the stored blocks at another lambda otherwise
     if (fresh) CAMCAL_DRV_TRY(camcal_cross_schur(M, tiles, intr2[cur], pose2[cur], V2[cur], g2[cur], lam, W, schur, scratch, stream));
     else CAMCAL_DRV_TRY(camcal_schur(M, tiles, V2[cur], W, g2[cur], lam, schur, scratch, stream));
@@ -254,7 +285,8 @@ struct PinholeLM {
     if (pending != TRIAL) return CAMCAL_E_BADARG;
     const int ng = camcal_glob_len(CAMCAL_PINHOLE);
     double back[8];
-    CAMCAL_DRV_TRY(rd.end(back, 8));
+    if (seq > 0.0) CAMCAL_DRV_TRY(rd.wait(seq, stream, back, 8));
+    else CAMCAL_DRV_TRY(rd.end(back, 8));
     err = back[7];
     if (back[4] == 0.0) return CAMCAL_E_NUMERIC;   // singular reduced system
     if (err > prev_err) {                          // rejected: the same blocks at ten times the damping
@@ -269,9 +301,14 @@ struct PinholeLM {
     ++iters;
     const double rel = std::sqrt(back[0] + back[5]) / std::sqrt(back[1] + back[6]);
     // accept: the trial point becomes the current one
-    CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_trial, ng, stream));
+    if (fused == 1) {                    // its record by reference; rec itself only when the loop ends
+      double* t = glob_cur; glob_cur = glob_tri; glob_tri = t;
+    } else {
+      CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_trial, ng, stream));
+    }
     cur = 1 - cur;
     if (iters >= max_iter || rel < eps) {
+      if (fused == 1 && glob_cur != rec) CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_cur, ng, stream));
       pending = DONE;
       return std::isfinite(err) ? 0 : CAMCAL_E_NUMERIC;
     }

@@ -1194,12 +1194,117 @@ __global__ __launch_bounds__(TPB) void k_reduce_solve(const double* __restrict__
     wave_lds_sync();
     if (threadIdx.x < 5) stats[threadIdx.x] = s_stats[threadIdx.x];
   }
-  // the scalars the host decides on, straight into its pinned memory: [stats (5) | cost | - | seq], seq last
+  // the scalars the host decides on, straight into its pinned memory: [stats (5) | cost | ... | seq], seq last
   if (notify && threadIdx.x == 0) {
     for (int i = 0; i < 5; ++i) notify[i] = do_solve ? s_stats[i] : 0.0;
     notify[5] = s_rec[NV - 1];
     __threadfence_system();
-    __hip_atomic_store(&notify[7], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&notify[CAMCAL_NOTIFY_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// ---- the same folding for the pinhole LM step of a small set -------------------------------------------
+// (1) sums of the Schur partial records + the reduced solve (k_finalize[_strided] + k_solve_reduced);
+// (2) back-substitution + evaluation A at the trial point, per view (k_backsub + k_intr_normal_grp mode 2);
+// (3) sums of the trial record and the step norms, expansion, and the eight scalars of the accept / reject
+//     decision written to the host (k_finalize x 2 + k_expand + three copies).
+template <int NI>
+__global__ __launch_bounds__(TPB) void k_reduce_schur_solve(const double* __restrict__ scratch, int stride, int n_part,
+                                                            double* red, unsigned* counter, const double* glob, double* schur,
+                                                            unsigned mask, double lam, double scale, const double* intr_in,
+                                                            double* intr_out, double* dK, double* stats) {
+  constexpr int NS = trisz(NI) + NI, NG = NS + 1;
+  __shared__ double s_sh[TPB], s_glob[NG], s_schur[NS], s_st[9], s_in[9], s_out[9], s_stats[5];
+  __shared__ unsigned s_last;
+  const double v = block_row_sum(scratch + (size_t)blockIdx.x * stride, n_part, s_sh);
+  if (threadIdx.x == 0) {
+    red[blockIdx.x] = v;
+    __threadfence();
+    s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < NS) {
+    const double x = __hip_atomic_load(&red[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_schur[threadIdx.x] = x;
+    schur[threadIdx.x] = x;
+  }
+  if (threadIdx.x < NG) s_glob[threadIdx.x] = glob[threadIdx.x];
+  if (threadIdx.x == 0) *counter = 0u;
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  solve_reduced_wave(NI, s_glob, s_schur, mask, lam, scale, intr_in, intr_out, dK, s_stats, s_st, s_in, s_out);
+  wave_lds_sync();
+  if (threadIdx.x < 5) stats[threadIdx.x] = s_stats[threadIdx.x];
+}
+
+template <int MODEL, int G>
+__global__ __launch_bounds__(TPB) void k_backsub_eval_grp(camcal_tiles t, const double* __restrict__ Vb,
+                                                          const double* __restrict__ Wb, const double* __restrict__ gb,
+                                                          double lam, const double* __restrict__ dK,
+                                                          const double* __restrict__ pose_in, double* __restrict__ pose_out,
+                                                          const double* __restrict__ intr_trial, double* __restrict__ V_out,
+                                                          double* __restrict__ g_out, double* __restrict__ scratch, int stride) {
+  constexpr int NI = MT<MODEL>::NI, NR = IntrAcc<MODEL>::NR;
+  GroupView gv;
+  if (!group_view<G>(t, gv)) return;
+  const int wave = (int)(((int64_t)blockIdx.x * TPB + threadIdx.x) >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t S = t.n_slots;
+  double dk[NI], I[NI], prev[6], out[6];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) dk[i] = dK[i];
+  load_pose(pose_in, S, gv.slot, prev);
+  double acc[2] = {0.0, 0.0};
+  if (gv.n > 0) {                      // every lane of the group: the same 6 x 6 solve on the same blocks
+    double dd, pp;
+    lane_backsub<NI>(Vb, Wb, gb, S, gv.slot, lam, dk, prev, out, dd, pp);
+    if (gv.gl == 0) { acc[0] = dd; acc[1] = pp; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[c] = prev[c];
+  }
+  if (gv.gl == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pose_out[c * S + gv.slot] = out[c];
+  }
+  load_intr<NI>(intr_trial, I);
+  group_intr_normal<MODEL, 2, G>(gv, S, I, out, nullptr, V_out, g_out, scratch, stride);
+  wave_scatter_store<2>(acc, lane, scratch + (size_t)NR * stride + wave, stride);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(TPB) void k_reduce_trial(const double* __restrict__ scratch, int n_part, double* red,
+                                                      unsigned* counter, double* __restrict__ glob_trial,
+                                                      double* __restrict__ norms, const double* __restrict__ stats,
+                                                      double* notify, double seq) {
+  constexpr int NR = IntrAcc<MODEL>::NR, NV = IntrAcc<MODEL>::NV;
+  __shared__ double s_sh[TPB], s_red[NR + 2], s_rec[NV];
+  __shared__ unsigned s_last;
+  const double v = block_row_sum(scratch + (size_t)blockIdx.x * n_part, n_part, s_sh);
+  if (threadIdx.x == 0) {
+    red[blockIdx.x] = v;
+    __threadfence();
+    s_last = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < NR + 2) s_red[threadIdx.x] = __hip_atomic_load(&red[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *counter = 0u;
+    IntrAcc<MODEL>::expand(s_red, s_rec);
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) glob_trial[threadIdx.x] = s_rec[threadIdx.x];
+  if (threadIdx.x < 2) norms[threadIdx.x] = s_red[NR + threadIdx.x];
+  if (notify && threadIdx.x == 0) {     // [stats (5) | step norms (2) | cost | ... | seq], seq last
+    for (int i = 0; i < 5; ++i) notify[i] = stats[i];
+    notify[5] = s_red[NR]; notify[6] = s_red[NR + 1]; notify[7] = s_rec[NV - 1];
+    __threadfence_system();
+    __hip_atomic_store(&notify[CAMCAL_NOTIFY_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -1614,6 +1719,86 @@ int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, d
   hipLaunchKernelGGL(k_reduce_solve<FISHEYE>, dim3(rows), dim3(TPB), 0, (hipStream_t)stream, scratch, np,
                      small_set_red(tiles, G, rows, scratch), small_set_counter(tiles, G, rows, scratch), rec, do_solve, mask,
                      lam, scale, intr_in, intr_out, dK, stats, notify, seq);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// pinhole LM step of a small set: reduced values and the last-workgroup counter at a fixed place behind
+// every layout of partial records these launches use
+static inline double* lm_red(double* scratch) { return scratch + (size_t)MAX_NV * PARTIAL_STRIDE; }
+static inline unsigned* lm_counter(double* scratch) { return (unsigned*)(lm_red(scratch) + 2 * MAX_NV - 8); }
+static inline unsigned mask_bits(const uint8_t* mask_host, int ni) {
+  unsigned m = 0;
+  for (int a = 0; a < ni; ++a)
+    if (mask_host[a]) m |= 1u << a;
+  return m;
+}
+
+int camcal_small_set_begin(int model, const camcal_tiles* tiles, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !scratch) return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  if (group_lanes(tiles) <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  HIP_TRY(hipMemsetAsync(lm_counter(scratch), 0, sizeof(unsigned), (hipStream_t)stream));
+  return 0;
+}
+
+int camcal_cross_schur_solve(int model, const camcal_tiles* tiles, const double* intr, const double* pose, const double* V,
+                             const double* g, double lam, double* W_out, const double* glob, double* schur,
+                             const uint8_t* mask_host, double scale, double* intr_out, double* dK, double* stats,
+                             double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !V || !g || !glob || !schur || !mask_host || !intr_out || !dK ||
+      !stats || !scratch)
+    return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int G = group_lanes(tiles);
+  if (G <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  const int np = tiles->n_tiles * G, ns = camcal_schur_len(model);
+  const dim3 gg(grid_groups(tiles, G)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 64) hipLaunchKernelGGL((k_cross_schur_grp<PINHOLE, 64>), gg, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, np);
+  else hipLaunchKernelGGL((k_cross_schur_grp<PINHOLE, 16>), gg, b, 0, s, *tiles, intr, pose, V, g, lam, W_out, scratch, np);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_schur_solve<9>, dim3(ns), b, 0, s, scratch, np, np, lm_red(scratch), lm_counter(scratch), glob,
+                     schur, mask_bits(mask_host, 9), lam, scale, intr, intr_out, dK, stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_schur_solve(int model, const camcal_tiles* tiles, const double* V, const double* W, const double* g, double lam,
+                       const double* glob, double* schur, const uint8_t* mask_host, double scale, const double* intr_in,
+                       double* intr_out, double* dK, double* stats, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !V || !W || !g || !glob || !schur || !mask_host || !intr_in || !intr_out || !dK || !stats || !scratch)
+    return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  if (group_lanes(tiles) <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  const int gp = grid_persistent(tiles), ns = camcal_schur_len(model);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_schur<9>, dim3(gp), dim3(TPB), 0, s, *tiles, V, W, g, lam, scratch);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_schur_solve<9>, dim3(ns), dim3(TPB), 0, s, scratch, PARTIAL_STRIDE, gp * WPB, lm_red(scratch),
+                     lm_counter(scratch), glob, schur, mask_bits(mask_host, 9), lam, scale, intr_in, intr_out, dK, stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int camcal_backsub_intr_normal(int model, const camcal_tiles* tiles, const double* V, const double* W, const double* g,
+                               double lam, const double* dK, const double* pose_in, double* pose_out,
+                               const double* intr_trial, double* glob_trial, double* V_trial, double* g_trial, double* norms,
+                               const double* stats, double* notify, double seq, double* scratch, void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !V || !W || !g || !dK || !pose_in || !pose_out || !intr_trial || !glob_trial ||
+      !V_trial || !g_trial || !norms || !stats || !scratch)
+    return CAMCAL_E_BADARG;
+  if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
+  const int G = group_lanes(tiles);
+  if (G <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  const int np = tiles->n_tiles * G;
+  const dim3 gg(grid_groups(tiles, G)), b(TPB);
+  hipStream_t s = (hipStream_t)stream;
+  if (G == 64) hipLaunchKernelGGL((k_backsub_eval_grp<PINHOLE, 64>), gg, b, 0, s, *tiles, V, W, g, lam, dK, pose_in, pose_out, intr_trial, V_trial, g_trial, scratch, np);
+  else hipLaunchKernelGGL((k_backsub_eval_grp<PINHOLE, 16>), gg, b, 0, s, *tiles, V, W, g, lam, dK, pose_in, pose_out, intr_trial, V_trial, g_trial, scratch, np);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_reduce_trial<PINHOLE>, dim3(IntrAcc<PINHOLE>::NR + 2), b, 0, s, scratch, np, lm_red(scratch),
+                     lm_counter(scratch), glob_trial, norms, stats, notify, seq);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -2114,7 +2299,7 @@ struct ReadBack {
   hipEvent_t ev = nullptr;
   int dev = -1;
 };
-constexpr int NOTIFY_SEQ = 7;
+constexpr int NOTIFY_SEQ = CAMCAL_NOTIFY_SEQ;
 std::mutex g_rb_mu;
 std::vector<ReadBack*> g_rb_free;
 

@@ -425,6 +425,33 @@ class Engine:
                    1 if solve else 0, self._mask_bytes(mask), float(lam), float(scale), self.intr[intr_in].data_ptr(),
                    self.intr[intr_out].data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(), None, 0.0, self._stream())
 
+    # -- the folded pinhole LM step of small sets (camcal_pinhole_lm runs these) ---------
+    def small_set_begin(self):
+        self._call("camcal_small_set_begin", self.model, self._tp(), self.scratch.data_ptr(), self._stream())
+
+    def cross_schur_solve(self, intr_in, pose_idx, lam, mask, scale, intr_out):
+        """camcal_cross_schur + camcal_solve_reduced(glob[0], schur) in two launches."""
+        self._call("camcal_cross_schur_solve", self.model, self._tp(), self.intr[intr_in].data_ptr(),
+                   self.pose[pose_idx].data_ptr(), self.V.data_ptr(), self.g.data_ptr(), float(lam), self.W.data_ptr(),
+                   self.glob[0].data_ptr(), self.schur.data_ptr(), self._mask_bytes(mask), float(scale),
+                   self.intr[intr_out].data_ptr(), self.dK.data_ptr(), self.stats.data_ptr(), self.scratch.data_ptr(),
+                   self._stream())
+
+    def schur_solve(self, lam, mask, scale, intr_in, intr_out):
+        """camcal_schur (stored blocks) + camcal_solve_reduced in two launches."""
+        self._call("camcal_schur_solve", self.model, self._tp(), self.V.data_ptr(), self.W.data_ptr(), self.g.data_ptr(),
+                   float(lam), self.glob[0].data_ptr(), self.schur.data_ptr(), self._mask_bytes(mask), float(scale),
+                   self.intr[intr_in].data_ptr(), self.intr[intr_out].data_ptr(), self.dK.data_ptr(),
+                   self.stats.data_ptr(), self.scratch.data_ptr(), self._stream())
+
+    def backsub_intr_normal(self, lam, pose_in, pose_out, intr_trial):
+        """camcal_backsub + camcal_intr_normal (with blocks, into the other V / g buffers and glob[1]) in two launches."""
+        self._call("camcal_backsub_intr_normal", self.model, self._tp(), self.V.data_ptr(), self.W.data_ptr(),
+                   self.g.data_ptr(), float(lam), self.dK.data_ptr(), self.pose[pose_in].data_ptr(),
+                   self.pose[pose_out].data_ptr(), self.intr[intr_trial].data_ptr(), self.glob[1].data_ptr(),
+                   self.Vs[1].data_ptr(), self.gs[1].data_ptr(), self.norms.data_ptr(), self.stats.data_ptr(), None, 0.0,
+                   self.scratch.data_ptr(), self._stream())
+
     def reproj_err(self, intr_idx, pose_idx, f32_round=True):
         """Per-view ||proj - corners||_2 / n (caller's view order) and their mean."""
         out = torch.zeros(2, dtype=torch.float64, device=self.device)

@@ -259,13 +259,40 @@ int camcal_refine_normal_eq_partial(int model, const camcal_tiles* tiles, const 
 /* camcal_reduce_solve: the second stage of that evaluation (fixed-order sums, rec = [U|b|cost|C|d] as
  * camcal_normal_eq_fused leaves glob | schur) and, with do_solve, camcal_solve_reduced on it, in one
  * launch: the workgroup that finishes its row last (a counter in scratch) expands and solves.
- * notify (or NULL): the device-visible address of 8 doubles of pinned, coherent host memory
- * (hipHostMalloc + hipHostGetDevicePointer).  The launch itself writes [stats (5) | cost | - | seq]
- * there, seq last, so the host can act on the scalars as soon as they exist -- no copy on the stream
+ * notify (or NULL): the device-visible address of 16 doubles of pinned, coherent host memory
+ * (hipHostMalloc + hipHostGetDevicePointer).  The launch itself writes [stats (5) | cost | ... | seq at
+ * CAMCAL_NOTIFY_SEQ] there, seq last, so the host can act on the scalars as soon as they exist -- no copy on the stream
  * between this launch and the next, which is what a production-sized iteration would otherwise wait for. */
 int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, double* rec, int do_solve,
                         const uint8_t* mask_host, double lam, double scale, const double* intr_in,
                         double* intr_out, double* dK, double* stats, double* notify, double seq, void* stream);
+
+/* The same folding for the pinhole LM step (CvLevMarq on the eliminated system, camera_calib.py:153-156) of a
+ * small set: 8 launches + 4 copies per step become 4 launches.  NO COUNTERPART IN THE REFERENCE.
+ * CAMCAL_E_UNSUPPORTED for large sets and for the fisheye model (camcal_pinhole_lm then runs the stages).
+ *   camcal_small_set_begin        once per solve on a scratch, before the calls below (clears their counter)
+ *   camcal_cross_schur_solve      camcal_cross_schur at (intr, pose) + camcal_solve_reduced(glob, schur, lam, scale,
+ *                                 intr -> intr_out); two launches (the second sums the partial records and solves)
+ *   camcal_schur_solve            camcal_schur (stored blocks at another lambda) + camcal_solve_reduced likewise
+ *   camcal_backsub_intr_normal    camcal_backsub (pose_in -> pose_out) + camcal_intr_normal with blocks at
+ *                                 (intr_trial, pose_out) -> glob_trial, V_trial, g_trial; norms, and with notify the
+ *                                 decision's scalars [stats (5, as left by the solve) | norms (2) | cost | ... | seq]
+ *                                 straight to the host; two launches
+ * Results equal the separate stages' to the order of the sums (1e-13 relative). */
+int camcal_small_set_begin(int model, const camcal_tiles* tiles, double* scratch, void* stream);
+int camcal_cross_schur_solve(int model, const camcal_tiles* tiles, const double* intr, const double* pose,
+                             const double* V, const double* g, double lam, double* W_out, const double* glob,
+                             double* schur, const uint8_t* mask_host, double scale, double* intr_out, double* dK,
+                             double* stats, double* scratch, void* stream);
+int camcal_schur_solve(int model, const camcal_tiles* tiles, const double* V, const double* W, const double* g,
+                       double lam, const double* glob, double* schur, const uint8_t* mask_host, double scale,
+                       const double* intr_in, double* intr_out, double* dK, double* stats, double* scratch,
+                       void* stream);
+int camcal_backsub_intr_normal(int model, const camcal_tiles* tiles, const double* V, const double* W,
+                               const double* g, double lam, const double* dK, const double* pose_in,
+                               double* pose_out, const double* intr_trial, double* glob_trial, double* V_trial,
+                               double* g_trial, double* norms, const double* stats, double* notify, double seq,
+                               double* scratch, void* stream);
 
 /* ---- Multi-GPU: views shard across ranks (one process per GPU); the only data exchanged are
  * the small global records, summed over the ranks between the stages of a solve.  The
@@ -273,6 +300,10 @@ int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, d
  * to sum: allreduce_sum(ctx, buf, n, stream) adds the n doubles at buf (device memory) over
  * all ranks in place, ordered on `stream` (it must not block the host on other ranks'
  * progress beyond what the collective itself needs), and returns 0 on success. */
+/* Slot of the sequence number in a notify buffer (camcal_reduce_solve, camcal_backsub_intr_normal): 16 doubles
+ * of pinned, coherent host memory; the launch writes its scalars to the first slots and the number last. */
+#define CAMCAL_NOTIFY_SEQ 15
+
 typedef struct camcal_comm {
   int (*allreduce_sum)(void* ctx, double* buf, int64_t n, void* stream);
   void* ctx;

@@ -531,7 +531,56 @@ int camcal_reduce_solve(int model, const camcal_tiles* t, double* scratch, doubl
   if (notify) {
     for (int i = 0; i < 5; ++i) notify[i] = do_solve ? stats[i] : 0.0;
     notify[5] = rec[ng - 1];
-    notify[7] = seq;
+    notify[CAMCAL_NOTIFY_SEQ] = seq;
+  }
+  return 0;
+}
+// the folded pinhole LM step of small sets: compositions of the stages
+static int small_pinhole(int model, const camcal_tiles* t) {
+  if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
+  return (lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view) <= 1 || model != 0) ? CAMCAL_E_UNSUPPORTED : 0;
+}
+int camcal_small_set_begin(int model, const camcal_tiles* t, double* scratch, void*) {
+  if (!t || !scratch) return CAMCAL_E_BADARG;
+  return small_pinhole(model, t);
+}
+int camcal_cross_schur_solve(int model, const camcal_tiles* t, const double* intr, const double* pose, const double* V,
+                             const double* g, double lam, double* W_out, const double* glob, double* schur_out,
+                             const uint8_t* mask_host, double scale, double* intr_out, double* dK, double* stats,
+                             double* scratch, void* s) {
+  if (!t || !intr || !pose || !V || !g || !glob || !schur_out || !mask_host || !intr_out || !dK || !stats || !scratch)
+    return CAMCAL_E_BADARG;
+  int rc = small_pinhole(model, t);
+  if (rc) return rc;
+  rc = camcal_cross_schur(model, t, intr, pose, V, g, lam, W_out, schur_out, scratch, s);
+  return rc ? rc : camcal_solve_reduced(model, glob, schur_out, mask_host, lam, scale, intr, intr_out, dK, stats, s);
+}
+int camcal_schur_solve(int model, const camcal_tiles* t, const double* V, const double* W, const double* g, double lam,
+                       const double* glob, double* schur_out, const uint8_t* mask_host, double scale, const double* intr_in,
+                       double* intr_out, double* dK, double* stats, double* scratch, void* s) {
+  if (!t || !V || !W || !g || !glob || !schur_out || !mask_host || !intr_in || !intr_out || !dK || !stats || !scratch)
+    return CAMCAL_E_BADARG;
+  int rc = small_pinhole(model, t);
+  if (rc) return rc;
+  rc = camcal_schur(model, t, V, W, g, lam, schur_out, scratch, s);
+  return rc ? rc : camcal_solve_reduced(model, glob, schur_out, mask_host, lam, scale, intr_in, intr_out, dK, stats, s);
+}
+int camcal_backsub_intr_normal(int model, const camcal_tiles* t, const double* V, const double* W, const double* g, double lam,
+                               const double* dK, const double* pose_in, double* pose_out, const double* intr_trial,
+                               double* glob_trial, double* V_trial, double* g_trial, double* norms, const double* stats,
+                               double* notify, double seq, double* scratch, void* s) {
+  if (!t || !V || !W || !g || !dK || !pose_in || !pose_out || !intr_trial || !glob_trial || !V_trial || !g_trial || !norms ||
+      !stats || !scratch)
+    return CAMCAL_E_BADARG;
+  int rc = small_pinhole(model, t);
+  if (rc) return rc;
+  rc = camcal_backsub(model, t, V, W, g, lam, dK, pose_in, pose_out, norms, scratch, s);
+  if (rc == 0) rc = camcal_intr_normal(model, t, intr_trial, pose_out, 1, glob_trial, nullptr, V_trial, g_trial, scratch, s);
+  if (rc) return rc;
+  if (notify) {
+    for (int i = 0; i < 5; ++i) notify[i] = stats[i];
+    notify[5] = norms[0]; notify[6] = norms[1]; notify[7] = glob_trial[camcal_glob_len(model) - 1];
+    notify[CAMCAL_NOTIFY_SEQ] = seq;
   }
   return 0;
 }
@@ -759,7 +808,7 @@ struct camcal_reader {
   double seq = 0.0;
   double* notify(double* seq_out) { seq += 1.0; *seq_out = seq; return landing; }
   int wait(double want, void*, double* dst_host, int n) {
-    if (landing[7] != want || n <= 0 || n > 7) return CAMCAL_E_BADARG;
+    if (landing[CAMCAL_NOTIFY_SEQ] != want || n <= 0 || n > CAMCAL_NOTIFY_SEQ) return CAMCAL_E_BADARG;
     std::memcpy(dst_host, landing, (size_t)n * sizeof(double));
     return 0;
   }

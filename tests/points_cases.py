@@ -589,6 +589,63 @@ def case_two_launch_iteration_of_small_sets():
 ALL.append(case_two_launch_iteration_of_small_sets)
 
 
+def case_folded_pinhole_lm_step_of_small_sets():
+    """camcal_cross_schur_solve / camcal_schur_solve / camcal_backsub_intr_normal (what camcal_pinhole_lm runs on small
+    sets: four launches per LM step) against the eight separate stage launches: Schur record, intrinsic step, trial
+    poses, trial record and blocks, step norms -- equal to the order of the sums; 16 and 64 lanes per view; one lane
+    per view and the fisheye model are refused (the stages run then)."""
+    from cameracalibration_amd import api, _lib
+    from cameracalibration_amd.engine import Engine
+    lib, dev = api._resolve()
+    P = synth.config("C1R", n_views=150)
+    K = P.K_guess
+    g0 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]] + list(np.asarray(P.D_guess).ravel()[:5]))
+    mask = np.ones(9, dtype=bool)
+
+    def close(x, y, tol=1e-11):
+        return np.abs(x - y).max() <= tol * max(np.abs(x).max(), 1e-300)
+    for lpv in (16, 64):
+        A = Engine(_lib.PINHOLE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
+        B = Engine(_lib.PINHOLE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
+        for E in (A, B):
+            E.set_intr(0, g0)
+            E.pose_init(0, 0)
+            E.pose_refine(0, 0, 20, 1e-10)
+            E.intr_normal(0, 0, 0, blocks=0)
+        B.small_set_begin()
+        for lam, fresh in ((1e-3, True), (1e-2, False)):
+            if fresh:
+                A.cross_schur(0, 0, lam)
+                B.cross_schur_solve(0, 0, lam, mask, -1.0, 1)
+            else:
+                A.schur_complement(lam)
+                B.schur_solve(lam, mask, -1.0, 0, 1)
+            A.solve_reduced(0, mask, lam, -1.0, 0, 1)
+            assert close(A.schur.cpu().numpy(), B.schur.cpu().numpy()), (lpv, lam)
+            assert close(A.dK.cpu().numpy()[:9], B.dK.cpu().numpy()[:9], 1e-8), (lpv, lam)
+            assert close(A.stats.cpu().numpy()[:5], B.stats.cpu().numpy()[:5], 1e-8)
+            assert close(A.get_intr(1), B.get_intr(1))
+            A.backsub(lam, 0, 1)
+            A.intr_normal(1, 1, 1, blocks=1)
+            B.backsub_intr_normal(lam, 0, 1, 1)
+            pa, pb = A.get_poses(1), B.get_poses(1)
+            assert np.abs(pa - pb).max() < 1e-8 * max(1.0, np.abs(pa).max()), (lpv, lam)
+            assert close(A.norms.cpu().numpy()[:2], B.norms.cpu().numpy()[:2], 1e-8)
+            assert close(A.glob[1].cpu().numpy(), B.glob[1].cpu().numpy(), 1e-8)
+            assert close(A.Vs[1].cpu().numpy(), B.Vs[1].cpu().numpy(), 1e-8) and close(A.gs[1].cpu().numpy(), B.gs[1].cpu().numpy(), 1e-6)
+        del A, B
+    for model, lpv, Pq in ((_lib.PINHOLE, 1, P), (_lib.FISHEYE, 64, synth.config("C3", n_views=30))):
+        E = Engine(model, Pq.view_ptr, Pq.obj, Pq.img, dev, lib=lib, lanes_per_view=lpv)
+        try:
+            E.small_set_begin()
+            raise AssertionError("must be refused")
+        except _lib.CamcalStatus as exc:
+            assert exc.code == _lib.E_UNSUPPORTED
+
+
+ALL.append(case_folded_pinhole_lm_step_of_small_sets)
+
+
 def case_one_call_entry_and_calibrate_many():
     """camcal_calibrate (what the plain drop-in call runs) against the stage-by-stage Engine path (chosen by
     passing _info), bit for bit; camcal_calibrate_many on the reference's four-camera loop (cali_in:
