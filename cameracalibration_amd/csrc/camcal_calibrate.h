@@ -230,9 +230,12 @@ struct Solve {
     double* pose = at<double>(c.pose0);
     // cvFindExtrinsicCameraParams2 / CalibrateExtrinsics per view: homography start + refinement
     CAMCAL_DRV_TRY(camcal_pose_init(p->model, &tiles, intr, pose, at<int32_t>(c.status), stream));
-    CAMCAL_DRV_TRY(camcal_pose_refine(p->model, &tiles, intr, pose, 20, 1e-10, at<int32_t>(c.iters), stream));
+    // (+ the first refinement: the fisheye loop folds it into its first launch where it can)
+    if (p->model != CAMCAL_FISHEYE)
+      CAMCAL_DRV_TRY(camcal_pose_refine(p->model, &tiles, intr, pose, 20, 1e-10, at<int32_t>(c.iters), stream));
     if (p->model == CAMCAL_FISHEYE) {
       gn.reset(new camcal_drv::FisheyeGN());
+      gn->refine_first = true;
       gn->tiles = &tiles; gn->intr = intr; gn->pose = pose; gn->mask_host = mask; gn->crit_type = crit_type;
       gn->max_count = max_iter; gn->eps = eps; gn->recompute_extrinsic = (p->flags & FE_RECOMPUTE) ? 1 : 0;
       gn->rec = at<double>(c.rec); gn->dK = at<double>(c.dK); gn->stats = at<double>(c.stats);

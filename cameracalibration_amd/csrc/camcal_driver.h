@@ -60,6 +60,7 @@ struct FisheyeGN {
   camcal_reader rd;
   double change = 1.0, cost = 0.0;
   int it = 0;
+  bool refine_first = false;            // the caller's poses come straight from the initialisation: refine them first
   int fused = -1;                       // small sets: two launches per iteration (-1: not tried yet, 0: no)
   bool have_partials = false;           // an evaluation at the current point waits in scratch
   double seq = 0.0;                     // > 0: the scalars of this step come through the reader's notify buffer
@@ -80,14 +81,15 @@ struct FisheyeGN {
       // (camcal_reduce_solve, camcal_refine_normal_eq_partial).  The evaluation at the point the loop
       // stops at has then been made already: its cost is the result's, no pass of its own.
       const bool respond = Y && recompute_extrinsic;
-      if (!have_partials) {
-        const int rc = camcal_refine_normal_eq_partial(CAMCAL_FISHEYE, tiles, intr, pose, 0, 1e-10, iters,
+      if (!have_partials) {              // (with refine_first: the first refinement rides along)
+        const int rc = camcal_refine_normal_eq_partial(CAMCAL_FISHEYE, tiles, intr, pose, refine_first ? 20 : 0, 1e-10, iters,
                                                        respond ? Y : nullptr, 0, dK, 0.0, 20, 1, scratch, stream);
         if (rc == CAMCAL_E_UNSUPPORTED && fused < 0) fused = 0;
         else {
           CAMCAL_DRV_TRY(rc);
           fused = 1;
           have_partials = true;
+          refine_first = false;
         }
       }
       if (fused == 1) {
@@ -111,6 +113,10 @@ struct FisheyeGN {
         pending = ITERATION;
         return 0;
       }
+    }
+    if (refine_first) {
+      CAMCAL_DRV_TRY(camcal_pose_refine(CAMCAL_FISHEYE, tiles, intr, pose, 20, 1e-10, iters, stream));
+      refine_first = false;
     }
     if (stop) {
       CAMCAL_DRV_TRY(camcal_intr_normal(CAMCAL_FISHEYE, tiles, intr, pose, 0, rec, nullptr, nullptr, nullptr, scratch,
