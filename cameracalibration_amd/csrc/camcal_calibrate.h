@@ -26,6 +26,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -104,6 +105,14 @@ inline Carve carve(int model, int64_t n_views, int64_t n_obs, int32_t T, int64_t
 
 // pinned staging above this size is not worth its copy (and would pin gigabytes for the large sets)
 constexpr size_t PIN_LIMIT = (size_t)8 << 20;
+// CAMCAL_PIN_LIMIT (bytes, read once) overrides it: 0 sends every call down the direct-copy path (tests)
+inline size_t pin_limit() {
+  static const size_t v = [] {
+    const char* e = std::getenv("CAMCAL_PIN_LIMIT");
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : PIN_LIMIT;
+  }();
+  return v;
+}
 
 struct Solve {
   camcal_problem* p = nullptr;
@@ -202,7 +211,7 @@ struct Solve {
                                  (int64_t*)(head.data() + c.tile_off)));
     std::memcpy(head.data() + c.view_ptr, p->view_ptr, (size_t)(N + 1) * 8);
     const size_t pin_bytes = c.up_bytes > c.res_bytes ? c.up_bytes : c.res_bytes;
-    if (pin_bytes <= PIN_LIMIT) pin = camcal_pinned_take(pin_bytes);
+    if (pin_bytes <= pin_limit()) pin = camcal_pinned_take(pin_bytes);
     if (pin) {                                    // one block, one copy
       char* u = (char*)pin;
       std::memcpy(u, head.data(), c.tables_bytes);

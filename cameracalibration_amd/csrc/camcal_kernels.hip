@@ -2372,7 +2372,8 @@ struct camcal_reader {
   // and which number; wait() = spin on the number, looking at the stream now and then so that a launch that
   // died does not leave the host spinning.
   double* notify(double* seq_out) {
-    if (acquire() != 0 || !rb->mapped) return nullptr;
+    static const bool off = std::getenv("CAMCAL_NO_NOTIFY") != nullptr;      // tests: the copy + event path instead
+    if (off || acquire() != 0 || !rb->mapped) return nullptr;
     rb->seq += 1.0;
     *seq_out = rb->seq;
     return rb->mapped;

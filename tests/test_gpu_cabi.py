@@ -26,3 +26,36 @@ def test_c_host_program_calibrates_a_rig_through_the_abi():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
+
+
+_FALLBACK_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import cameracalibration_amd as cc
+from cameracalibration_amd import synth
+out = []
+for name, fn, fl in (("C2", cc.fisheye.calibrate, 8 | 2 | 1), ("C1", cc.calibrateCamera, 1)):
+    P = synth.config(name, n_views=60 if name == "C2" else 20)
+    o, i = P.as_lists()
+    r = fn(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=(3, 1000, 1e-6))
+    out.append(np.concatenate([[r[0]], r[1].ravel(), np.asarray(r[2]).ravel(), np.hstack(r[3]).ravel(), np.hstack(r[4]).ravel()]))
+np.save(sys.argv[1], np.concatenate(out))
+"""
+
+
+@pytest.mark.gpu
+def test_one_call_entry_on_its_fallback_transfer_paths(tmp_path):
+    """camcal_calibrate without pinned staging (CAMCAL_PIN_LIMIT=0: the copies go from / to the caller's arrays, the
+    path of sets above 8 MB) and without the kernel-written notify buffer (CAMCAL_NO_NOTIFY: copy + event read-backs):
+    the same results to the bit as the default paths -- only the transfers differ."""
+    import numpy as np
+    res = {}
+    for tag, env in (("default", {}), ("direct", {"CAMCAL_PIN_LIMIT": "0"}), ("copies", {"CAMCAL_NO_NOTIFY": "1"}),
+                     ("both", {"CAMCAL_PIN_LIMIT": "0", "CAMCAL_NO_NOTIFY": "1"})):
+        f = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([os.sys.executable, "-c", _FALLBACK_SCRIPT % ROOT, f], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    for tag in ("direct", "copies", "both"):
+        assert np.array_equal(res[tag], res["default"]), tag
