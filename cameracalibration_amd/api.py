@@ -598,7 +598,8 @@ class CalibrationSession:
 
     The reference's capture loops call the solver after every accepted frame with the
     same lists, one view longer (intrinsicCalib.py:538-564 -> ``Fisheye/Normal.update``
-    :86-94, 100 iterations first, then 10-iteration refinements :129-135).  A session
+    :86-94, 100 iterations first, then 10-iteration refinements :129-135).  For lists of
+    ``ONE_SHOT_BELOW`` corner observations or more a session
     keeps the packed views and the solver state on the device: a call whose lists start
     with the very arrays of the previous call (checked by identity) uploads and packs only
     the new views, initialises only their poses and warm-starts the others from the
@@ -606,12 +607,32 @@ class CalibrationSession:
     -- to the refinement tolerance -- the same numbers as the one-shot functions
     (``tests/test_hostlogic.py::test_session_*``)."""
 
+    # Lists with fewer corner observations than this go through the one-call path, from scratch, as cv2 does:
+    # at production sizes (the reference keeps <= 25 views of <= 88 corners per camera) a fresh one-call solve
+    # (0.4 - 0.5 ms at 10 ... 80 views) is faster than keeping the device state up to date from Python
+    # (0.6 - 0.7 ms: tools/gpu_session.py); what a session saves -- the upload, packing and pose initialisation
+    # of the views already held -- only outweighs that for large growing sets.
+    ONE_SHOT_BELOW = 100_000
+
     def __init__(self, model):
         if model not in ("pinhole", "fisheye"):
             raise error("model must be 'pinhole' or 'fisheye'")
         self.model = model
         self._E = None
         self._held = []                 # (object array, image array) of every view on the device
+
+    def _small(self, objectPoints, _info):
+        """Production-sized lists: the plain one-call solve (any device state is dropped)."""
+        if _info is not None or self.ONE_SHOT_BELOW <= 0:
+            return False
+        try:
+            n = sum(map(len, objectPoints))
+        except TypeError:
+            return False
+        if n >= self.ONE_SHOT_BELOW:
+            return False
+        self._E, self._held = None, []
+        return True
 
     def _sync(self, objectPoints, imagePoints):
         """Bring the engine to the given lists; returns the slots of the views added."""
@@ -637,6 +658,8 @@ class CalibrationSession:
                         flags=0, criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 30, DBL_EPSILON), *, _info=None):
         if self.model != "pinhole":
             raise error("this session holds a fisheye camera")
+        if self._small(objectPoints, _info):
+            return calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoeffs, rvecs, tvecs, flags, criteria)
         flags = int(flags)
         D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
         E, dev, slots = self._sync(objectPoints, imagePoints)
@@ -649,6 +672,8 @@ class CalibrationSession:
                   criteria=(TERM_CRITERIA_COUNT + TERM_CRITERIA_EPS, 100, DBL_EPSILON), *, _info=None):
         if self.model != "fisheye":
             raise error("this session holds a pinhole camera")
+        if self._small(objectPoints, _info):
+            return fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs, tvecs, flags, criteria)
         flags = int(flags)
         intr0, mask = _prep_fisheye(K, D, flags)
         E, dev, slots = self._sync(objectPoints, imagePoints)

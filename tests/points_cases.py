@@ -347,6 +347,11 @@ def case_session_growing_lists():
         inc = ses.calibrate if model == "fisheye" else ses.calibrateCamera
         K, D = P.K_guess.copy(), P.D_guess.copy()
         Kf, Df = P.K_guess.copy(), P.D_guess.copy()
+        # production-sized lists take the one-call path (a fresh solve is cheaper than the bookkeeping): same bits
+        a = inc(objs[:12], imgs[:12], P.image_size, K.copy(), D.copy(), flags=fl, criteria=(3, 100, 1e-6))
+        b = one(objs[:12], imgs[:12], P.image_size, Kf.copy(), Df.copy(), flags=fl, criteria=(3, 100, 1e-6))
+        assert ses._E is None and a[0] == b[0] and np.array_equal(a[1], b[1])
+        ses.ONE_SHOT_BELOW = 0                                  # from here on: the incremental machinery itself
         for step, n in enumerate((6, 7, 8, 30, 64, 65, 70)):
             crit = (3, 100 if step == 0 else 10, 1e-6)
             a = inc(objs[:n], imgs[:n], P.image_size, K, D, flags=fl, criteria=crit)

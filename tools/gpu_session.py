@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Growing-list caller (intrinsicCalib.py:538-564): per-call time of cc.CalibrationSession against
-fresh one-shot calls, one more view per call, 10-iteration refinements (development tool)."""
+"""Growing-list caller (intrinsicCalib.py:538-564): per-call time of cc.CalibrationSession's incremental path
+against fresh one-shot calls, one more view per call, 10-iteration refinements (development tool).  The
+measurement behind CalibrationSession.ONE_SHOT_BELOW."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,6 +13,7 @@ for model, cfg, fl in (("fisheye", "C2", FE), ("pinhole", "C1", 1)):
     objs, imgs = P.as_lists()
     for rep in range(2):
         ses = cc.CalibrationSession(model)
+        ses.ONE_SHOT_BELOW = 0          # the incremental machinery (production-sized lists would take the one-call path)
         one = cc.fisheye.calibrate if model == "fisheye" else cc.calibrateCamera
         inc = ses.calibrate if model == "fisheye" else ses.calibrateCamera
         K, D = P.K_guess.copy(), P.D_guess.copy()
