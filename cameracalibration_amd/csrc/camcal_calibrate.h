@@ -56,7 +56,7 @@ struct Carve {
   size_t img = 0, obj = 0, intr0 = 0, up_bytes = 0;
   size_t pose0 = 0, status = 0, res_bytes = 0;
   size_t pts = 0;
-  size_t intr1 = 0, pose1 = 0, V0 = 0, V1 = 0, g0 = 0, g1 = 0, W = 0, rec = 0, glob1 = 0, dK = 0, stats = 0,
+  size_t intr1 = 0, pose1 = 0, V0 = 0, V1 = 0, g0 = 0, g1 = 0, W1 = 0, intr_spare = 0, W = 0, rec = 0, glob1 = 0, dK = 0, stats = 0,
          scratch = 0, iters = 0;
   size_t total = 0;
 };
@@ -96,6 +96,8 @@ inline Carve carve(int model, int64_t n_views, int64_t n_obs, int32_t T, int64_t
     c.V1 = dbl(21 * (size_t)S);
     c.g0 = dbl(6 * (size_t)S);
     c.g1 = dbl(6 * (size_t)S);
+    c.W1 = dbl((size_t)ni * 6 * S);    // spare cross blocks + intrinsics: the LM loop runs half a step ahead (camcal_driver.h)
+    c.intr_spare = dbl(16);
   }
   c.scratch = dbl((size_t)camcal_scratch_len(model, T));
   c.iters = o; o = up(o + (size_t)S * 4);
@@ -261,6 +263,7 @@ struct Solve {
       lm->W = at<double>(c.W); lm->rec = at<double>(c.rec); lm->glob_trial = at<double>(c.glob1);
       lm->norms = at<double>(c.glob1) + camcal_glob_len(CAMCAL_PINHOLE);
       lm->dK = at<double>(c.dK); lm->stats = at<double>(c.stats); lm->scratch = at<double>(c.scratch);
+      lm->W_alt = at<double>(c.W1); lm->intr_spare = at<double>(c.intr_spare);
       lm->mask_host = mask; lm->max_iter = max_iter; lm->eps = eps; lm->comm = comm; lm->stream = stream;
       if (!lm->args_ok()) return CAMCAL_E_BADARG;
     }

@@ -199,6 +199,15 @@ struct PinholeLM {
   double* glob_cur = nullptr;          // fused: [U|b|cost] of the current point (rec or glob_trial, swapped on accept)
   double* glob_tri = nullptr;
   double seq = 0.0;                    // > 0: the step's scalars come through the reader's notify buffer
+  bool first_cost_pending = false;     // the starting cost arrives with the first step's scalars
+  // fused, with W_alt and intr_spare given: the first half of the NEXT step (evaluation B + reduced solve at the
+  // trial point, lambda / 10) is enqueued behind the current step before the host waits for its verdict, so that
+  // an accepted step -- the usual case -- finds it done; a rejected one ignores it (everything it wrote is spare)
+  double* W_alt = nullptr;
+  double* intr_spare = nullptr;
+  double *W_c = nullptr, *intr_c = nullptr, *intr_t = nullptr, *intr_s = nullptr;
+  bool spec_enqueued = false, spec_done = false;
+  int spec_lam_lg10 = 0;
   int lam_lg10 = -3, iters = 0;
   double err = 0.0, prev_err = 0.0;
   bool fresh = true;
@@ -229,30 +238,53 @@ struct PinholeLM {
       }
       glob_cur = rec;
       glob_tri = glob_trial;
+      W_c = W; intr_c = intr2[0]; intr_t = intr2[1]; intr_s = intr_spare;
       CAMCAL_DRV_TRY(camcal_intr_normal(M, tiles, intr2[cur], pose2[cur], 1, glob, nullptr, V2[cur], g2[cur], scratch,
                                         stream));
       CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, glob, ng, stream));
-      CAMCAL_DRV_TRY(rd.begin(glob + ng - 1, 1, 0, stream));
-      pending = FIRST_COST;
-      return 0;
+      if (fused == 1) {
+        // the first step does not depend on the starting cost, only its verdict does: launch it now and read the
+        // cost with the step's scalars (slot 8 of the landing buffer) -- one host round trip less per solve
+        CAMCAL_DRV_TRY(rd.begin(glob + ng - 1, 1, 8, stream));
+        first_cost_pending = true;
+        fresh = true;
+        pending = READY;
+      } else {
+        CAMCAL_DRV_TRY(rd.begin(glob + ng - 1, 1, 0, stream));
+        pending = FIRST_COST;
+        return 0;
+      }
     }
     if (pending != READY) return CAMCAL_E_BADARG;
     const int tri = 1 - cur;
     const double lam = std::pow(10.0, (double)lam_lg10);
     if (fused == 1) {
-      if (fresh) CAMCAL_DRV_TRY(camcal_cross_schur_solve(M, tiles, intr2[cur], pose2[cur], V2[cur], g2[cur], lam, W, glob_cur,
-                                                         schur, mask_host, -1.0, intr2[tri], dK, stats, scratch, stream));
-      else CAMCAL_DRV_TRY(camcal_schur_solve(M, tiles, V2[cur], W, g2[cur], lam, glob_cur, schur, mask_host, -1.0, intr2[cur],
-                                             intr2[tri], dK, stats, scratch, stream));
+      if (spec_done) {
+        spec_done = false;               // the previous launch() already did this step's first half
+      } else if (fresh) {
+        CAMCAL_DRV_TRY(camcal_cross_schur_solve(M, tiles, intr_c, pose2[cur], V2[cur], g2[cur], lam, W_c, glob_cur, schur,
+                                                mask_host, -1.0, intr_t, dK, stats, scratch, stream));
+      } else {
+        CAMCAL_DRV_TRY(camcal_schur_solve(M, tiles, V2[cur], W_c, g2[cur], lam, glob_cur, schur, mask_host, -1.0, intr_c,
+                                          intr_t, dK, stats, scratch, stream));
+      }
       seq = 0.0;
       double* note = rd.notify(&seq);
       if (!note) seq = 0.0;
-      CAMCAL_DRV_TRY(camcal_backsub_intr_normal(M, tiles, V2[cur], W, g2[cur], lam, dK, pose2[cur], pose2[tri], intr2[tri],
+      CAMCAL_DRV_TRY(camcal_backsub_intr_normal(M, tiles, V2[cur], W_c, g2[cur], lam, dK, pose2[cur], pose2[tri], intr_t,
                                                 glob_tri, V2[tri], g2[tri], norms, stats, note, seq, scratch, stream));
       if (!note) {
         CAMCAL_DRV_TRY(rd.begin(stats, 5, 0, stream));
         CAMCAL_DRV_TRY(rd.begin(norms, 2, 5, stream));
         CAMCAL_DRV_TRY(rd.begin(glob_tri + ng - 1, 1, 7, stream));
+      }
+      spec_enqueued = false;
+      if (W_alt && intr_s && iters + 1 < max_iter) {       // the next step's first half, should this one be accepted
+        spec_lam_lg10 = lam_lg10 - 1 < -16 ? -16 : lam_lg10 - 1;
+        CAMCAL_DRV_TRY(camcal_cross_schur_solve(M, tiles, intr_t, pose2[tri], V2[tri], g2[tri],
+                                                std::pow(10.0, (double)spec_lam_lg10), W_alt, glob_tri, schur, mask_host, -1.0,
+                                                intr_s, dK, stats, scratch, stream));
+        spec_enqueued = true;
       }
       pending = TRIAL;
       return 0;
@@ -290,15 +322,21 @@ struct PinholeLM {
     }
     if (pending != TRIAL) return CAMCAL_E_BADARG;
     const int ng = camcal_glob_len(CAMCAL_PINHOLE);
-    double back[8];
-    if (seq > 0.0) CAMCAL_DRV_TRY(rd.wait(seq, stream, back, 8));
-    else CAMCAL_DRV_TRY(rd.end(back, 8));
+    double back[9];
+    const int nb = first_cost_pending ? 9 : 8;
+    if (seq > 0.0) CAMCAL_DRV_TRY(rd.wait(seq, stream, back, nb));
+    else CAMCAL_DRV_TRY(rd.end(back, nb));
+    if (first_cost_pending) {
+      prev_err = back[8];
+      first_cost_pending = false;
+    }
     err = back[7];
     if (back[4] == 0.0) return CAMCAL_E_NUMERIC;   // singular reduced system
     if (err > prev_err) {                          // rejected: the same blocks at ten times the damping
       ++lam_lg10;
       if (lam_lg10 <= 16) {
         fresh = false;
+        spec_enqueued = false;                     // what ran ahead assumed acceptance: ignored
         pending = READY;
         return 0;
       }
@@ -309,12 +347,23 @@ struct PinholeLM {
     // accept: the trial point becomes the current one
     if (fused == 1) {                    // its record by reference; rec itself only when the loop ends
       double* t = glob_cur; glob_cur = glob_tri; glob_tri = t;
+      if (spec_enqueued && spec_lam_lg10 == lam_lg10) {      // ... and its evaluation B + solve have run already
+        t = W_c; W_c = W_alt; W_alt = t;
+        t = intr_c; intr_c = intr_t; intr_t = intr_s; intr_s = t;
+        spec_done = true;
+      } else {
+        t = intr_c; intr_c = intr_t; intr_t = t;
+      }
+      spec_enqueued = false;
     } else {
       CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_trial, ng, stream));
     }
     cur = 1 - cur;
     if (iters >= max_iter || rel < eps) {
-      if (fused == 1 && glob_cur != rec) CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_cur, ng, stream));
+      if (fused == 1) {                  // hand the result over where the caller expects it
+        if (glob_cur != rec) CAMCAL_DRV_TRY(camcal_copy_doubles(rec, glob_cur, ng, stream));
+        if (intr_c != intr2[cur]) CAMCAL_DRV_TRY(camcal_copy_doubles(intr2[cur], intr_c, 9, stream));
+      }
       pending = DONE;
       return std::isfinite(err) ? 0 : CAMCAL_E_NUMERIC;
     }

@@ -651,6 +651,31 @@ def case_folded_pinhole_lm_step_of_small_sets():
 ALL.append(case_folded_pinhole_lm_step_of_small_sets)
 
 
+def case_pinhole_lm_with_rejected_steps():
+    """Poor starting intrinsics make CvLevMarq reject steps (the damping sequence of the iteration log goes up as
+    well as down).  The one-call path -- which runs the first half of the next step ahead of the verdict and has to
+    drop it after a rejection (camcal_driver.h: PinholeLM) -- returns what the stage-by-stage loop returns."""
+    P = synth.config("C1R", n_views=40, seed=3)
+    objs, imgs = P.as_lists()
+    for scale, dd in ((1.6, 0.8), (2.5, 1.5)):
+        K = P.K_guess.copy()
+        K[0, 0] *= scale
+        K[1, 1] *= scale
+        D = np.asarray(P.D_guess, dtype=np.float64).copy()
+        D = D + dd * np.array([1, -1, 0.01, 0.01, 0.5]).reshape(D.shape)
+        a = cc.calibrateCamera(objs, imgs, P.image_size, K.copy(), D.copy(), flags=1, criteria=(3, 60, 1e-9))
+        info = dict(log=True)
+        b = cc.calibrateCamera(objs, imgs, P.image_size, K.copy(), D.copy(), flags=1, criteria=(3, 60, 1e-9), _info=info)
+        lam = [e["lam_lg10"] for e in info["log"]]
+        assert any(y >= x for x, y in zip(lam, lam[1:])), lam            # at least one rejection on the way
+        assert abs(a[0] - b[0]) < 1e-9 and abs(a[0] - 0.2709) < 1e-3
+        assert np.allclose(a[1], b[1], rtol=1e-8, atol=0) and np.allclose(a[2], b[2], rtol=1e-6, atol=1e-10)
+        assert np.allclose(np.hstack(a[3]), np.hstack(b[3]), atol=1e-8)
+
+
+ALL.append(case_pinhole_lm_with_rejected_steps)
+
+
 def case_one_call_entry_and_calibrate_many():
     """camcal_calibrate (what the plain drop-in call runs) against the stage-by-stage Engine path (chosen by
     passing _info), bit for bit; camcal_calibrate_many on the reference's four-camera loop (cali_in:
