@@ -684,7 +684,7 @@ def case_one_call_entry_and_calibrate_many():
     problem fails that problem and names the view."""
     FEc = FE
     crit = (3, 1000, 1e-6)
-    calls, single, engine = [], [], []
+    calls, single, engine, guesses = [], [], [], []
     for k, (name, model, nv, seed) in enumerate((("C3", "fisheye", 25, 31), ("C3", "fisheye", 21, 32),
                                                  ("C1R", "pinhole", 25, 33), ("C1", "pinhole", 20, 34))):
         P = synth.config(name, n_views=nv, seed=seed)
@@ -696,12 +696,20 @@ def case_one_call_entry_and_calibrate_many():
         engine.append(fn(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit, _info=info))
         calls.append(dict(model=model, objectPoints=objs, imagePoints=imgs, imageSize=P.image_size,
                           cameraMatrix=P.K_guess.copy(), distCoeffs=P.D_guess.copy(), flags=fl, criteria=crit))
+        guesses.append((P.K_guess.copy(), P.D_guess.copy()))
     many = cc.calibrate_many(calls)
     for a, b, e, c in zip(many, single, engine, calls):
         for x in (b, e):
             assert a[0] == x[0] and np.array_equal(a[1], x[1]) and np.array_equal(a[2], x[2])
             assert np.array_equal(np.hstack(a[3]), np.hstack(x[3])) and np.array_equal(np.hstack(a[4]), np.hstack(x[4]))
         assert a[1] is c["cameraMatrix"] and a[2] is c["distCoeffs"] and a[2].shape == c["distCoeffs"].shape
+    # more problems than the library has streams (they share them round robin): nine at once
+    nine = [dict(c, cameraMatrix=P0.copy(), distCoeffs=D0.copy())
+            for c, P0, D0 in ((calls[j % 4], guesses[j % 4][0], guesses[j % 4][1]) for j in range(9))]
+    for j, a in enumerate(cc.calibrate_many(nine)):
+        b = single[j % 4]
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.array_equal(np.hstack(a[3]), np.hstack(b[3]))
     # the 4-coefficient pinhole call through the one-call path: a new 5-element array comes back
     P = synth.config("C1", n_views=12)
     objs, imgs = P.as_lists()
