@@ -1674,6 +1674,11 @@ int camcal_pose_predict_refine(int model, const camcal_tiles* tiles, const doubl
   return pose_refine_impl(model, tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap, stream);
 }
 
+// which sets run the folded stages: camcal_lane.h, folded_set_of (with the measurements behind the limits)
+static inline bool folded_set(const camcal_tiles* tiles, int model) {
+  return folded_set_of(tiles->n_tiles, tiles->planar, tiles->lanes_per_view, model == CAMCAL_FISHEYE);
+}
+
 // where k_refine_eval_grp / k_reduce_solve keep their reduced values and their counter: behind the
 // partial records, as camcal_normal_eq_fused does for a grouped set
 static inline double* small_set_red(const camcal_tiles* tiles, int G, int rows, double* scratch) {
@@ -1690,7 +1695,7 @@ int camcal_refine_normal_eq_partial(int model, const camcal_tiles* tiles, const 
   if (predict && (!Y || !dK)) return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const int G = group_lanes(tiles);
-  if (G <= 1 || model != CAMCAL_FISHEYE) return CAMCAL_E_UNSUPPORTED;   // large sets: the stages on their own
+  if (model != CAMCAL_FISHEYE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;   // large sets: the stages on their own
   const int np = tiles->n_tiles * G;
   const int rows = IntrAcc<FISHEYE>::NR + camcal_schur_len(CAMCAL_FISHEYE);
   unsigned* counter = first ? small_set_counter(tiles, G, rows, scratch) : nullptr;
@@ -1709,7 +1714,7 @@ int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, d
   if (do_solve && (!mask_host || !intr_in || !intr_out || !dK || !stats)) return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const int G = group_lanes(tiles);
-  if (G <= 1 || model != CAMCAL_FISHEYE) return CAMCAL_E_UNSUPPORTED;
+  if (model != CAMCAL_FISHEYE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;
   const int np = tiles->n_tiles * G;
   const int rows = IntrAcc<FISHEYE>::NR + camcal_schur_len(CAMCAL_FISHEYE);
   unsigned mask = 0;
@@ -1737,7 +1742,7 @@ static inline unsigned mask_bits(const uint8_t* mask_host, int ni) {
 int camcal_small_set_begin(int model, const camcal_tiles* tiles, double* scratch, void* stream) {
   if (!tiles_ok(tiles) || !scratch) return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
-  if (group_lanes(tiles) <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  if (model != CAMCAL_PINHOLE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;
   HIP_TRY(hipMemsetAsync(lm_counter(scratch), 0, sizeof(unsigned), (hipStream_t)stream));
   return 0;
 }
@@ -1751,7 +1756,7 @@ int camcal_cross_schur_solve(int model, const camcal_tiles* tiles, const double*
     return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const int G = group_lanes(tiles);
-  if (G <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  if (model != CAMCAL_PINHOLE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;
   const int np = tiles->n_tiles * G, ns = camcal_schur_len(model);
   const dim3 gg(grid_groups(tiles, G)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
@@ -1770,7 +1775,7 @@ int camcal_schur_solve(int model, const camcal_tiles* tiles, const double* V, co
   if (!tiles_ok(tiles) || !V || !W || !g || !glob || !schur || !mask_host || !intr_in || !intr_out || !dK || !stats || !scratch)
     return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
-  if (group_lanes(tiles) <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  if (model != CAMCAL_PINHOLE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;
   const int gp = grid_persistent(tiles), ns = camcal_schur_len(model);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_schur<9>, dim3(gp), dim3(TPB), 0, s, *tiles, V, W, g, lam, scratch);
@@ -1790,7 +1795,7 @@ int camcal_backsub_intr_normal(int model, const camcal_tiles* tiles, const doubl
     return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const int G = group_lanes(tiles);
-  if (G <= 1 || model != CAMCAL_PINHOLE) return CAMCAL_E_UNSUPPORTED;
+  if (model != CAMCAL_PINHOLE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;
   const int np = tiles->n_tiles * G;
   const dim3 gg(grid_groups(tiles, G)), b(TPB);
   hipStream_t s = (hipStream_t)stream;

@@ -2,6 +2,7 @@
 // Shared by camcal_kernels.hip (device) and the tests' CPU lane emulator.
 // See camcal_math.h for conventions and the reference citations.
 #pragma once
+#include <cstdlib>
 #include "camcal_math.h"
 
 namespace camcal {
@@ -787,6 +788,25 @@ inline int lanes_per_view_of(int n_tiles, int planar, int want) {
   if (want == 64) return n_tiles <= GROUP64_MAX_TILES ? 64 : 1;
   if (want == 16) return n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
   return n_tiles <= GROUP64_MAX_TILES ? 64 : n_tiles <= GROUP16_MAX_TILES ? 16 : 1;
+}
+// Which sets run the folded stages (camcal_refine_normal_eq_partial ... camcal_backsub_intr_normal).  Pinhole LM
+// step: every set in a several-lanes-per-view mapping (loop time separate / folded, C1R sets, one box,
+// tools/gpu_pinhole_mid.py: 1000 views 0.57 / 0.50 ms, 6000 0.68 / 0.51, 12 000 0.81 / 0.64, 28 000 1.20 / 1.11).
+// Fisheye iteration: up to FOLD_MAX_WAVES wavefronts per launch -- its fused refinement + evaluation kernel runs at
+// the evaluation's one wavefront per SIMD, which costs the refinement its second wavefront once there is more than
+// a SIMD's worth of them (C2 sets, tools/gpu_c3_phases.py: 1000 views / 1000 wavefronts 0.59 / 0.52 ms, 2000 / 2048
+// 0.74 / 0.76, 3000 / 768 1.01 / 0.85, 6000 / 1536 1.15 / 1.01, 12 000 / 3072 1.55 / 1.58, 20 000 / 5120 1.97 / 2.28).
+// CAMCAL_FOLD_MAX_WAVES (read once) overrides the limit for both models (0: separate stages everywhere).
+constexpr int FOLD_MAX_WAVES = 1600;
+inline bool folded_set_of(int n_tiles, int planar, int want, bool fisheye) {
+  static const long forced = [] {
+    const char* e = std::getenv("CAMCAL_FOLD_MAX_WAVES");
+    return e ? std::atol(e) : -1L;
+  }();
+  const int G = lanes_per_view_of(n_tiles, planar, want);
+  if (G <= 1) return false;
+  if (forced >= 0) return (long)n_tiles * G <= forced;
+  return !fisheye || (long)n_tiles * G <= FOLD_MAX_WAVES;
 }
 inline long long static_partials(int n_tiles, int planar, int want) {
   return (long long)n_tiles * lanes_per_view_of(n_tiles, planar, want);

@@ -237,8 +237,9 @@ int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const do
                                   const double* pose, double lam, double* glob, double* schur,
                                   void* stream);
 
-/* ---- Small view sets (several lanes per view: planar, <= 28 672 views -- the reference's own calls hold
- * 20 ... 500), fisheye loop: two stages that fold the five launches of an iteration into two.  A
+/* ---- Small view sets (several lanes per view and at most 1600 wavefronts per launch: <= 1600 views at 64 lanes
+ * per view, 2049 ... 6400 at 16 -- the reference's own calls hold 20 ... 500), fisheye loop: two stages that fold
+ * the five launches of an iteration into two.  A
  * production-sized iteration is a chain of ~5 ... 60 us kernels whose length is set by the one or two views
  * that need 18 - 20 Gauss-Newton steps; every launch boundary and every separate small kernel on that
  * chain is wall clock.  CAMCAL_E_UNSUPPORTED for other sets and for the pinhole model (callers then use
@@ -268,8 +269,9 @@ int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, d
                         double* intr_out, double* dK, double* stats, double* notify, double seq, void* stream);
 
 /* The same folding for the pinhole LM step (CvLevMarq on the eliminated system, camera_calib.py:153-156) of a
- * small set: 8 launches + 4 copies per step become 4 launches.  NO COUNTERPART IN THE REFERENCE.
- * CAMCAL_E_UNSUPPORTED for large sets and for the fisheye model (camcal_pinhole_lm then runs the stages).
+ * set in a several-lanes-per-view mapping (planar, <= 28 672 views): 8 launches + 4 copies per step become 4
+ * launches.  NO COUNTERPART IN THE REFERENCE.
+ * CAMCAL_E_UNSUPPORTED for larger sets and for the fisheye model (camcal_pinhole_lm then runs the stages).
  *   camcal_small_set_begin        once per solve on a scratch, before the calls below (clears their counter)
  *   camcal_cross_schur_solve      camcal_cross_schur at (intr, pose) + camcal_solve_reduced(glob, schur, lam, scale,
  *                                 intr -> intr_out); two launches (the second sums the partial records and solves)

@@ -506,7 +506,7 @@ int camcal_refine_normal_eq_partial(int model, const camcal_tiles* t, const doub
                                     int cap, int, double* scratch, void* s) {
   if (!t || !intr || !pose || !scratch || max_iter < 0 || (predict && (!Y || !dK))) return CAMCAL_E_BADARG;
   if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
-  if (lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view) <= 1 || model != 1) return CAMCAL_E_UNSUPPORTED;
+  if (model != 1 || !folded_set_of(t->n_tiles, t->planar, t->lanes_per_view, true)) return CAMCAL_E_UNSUPPORTED;
   if (max_iter > 0) {
     const int rc = predict ? camcal_pose_predict_refine(model, t, intr, Y, dK, scale, cap, pose, max_iter, tol, iters, s)
                            : camcal_pose_refine(model, t, intr, pose, max_iter, tol, iters, s);
@@ -521,7 +521,7 @@ int camcal_reduce_solve(int model, const camcal_tiles* t, double* scratch, doubl
                         double* notify, double seq, void* s) {
   if (!t || !scratch || !rec || (do_solve && (!mask_host || !intr_in || !intr_out || !dK || !stats))) return CAMCAL_E_BADARG;
   if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
-  if (lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view) <= 1 || model != 1) return CAMCAL_E_UNSUPPORTED;
+  if (model != 1 || !folded_set_of(t->n_tiles, t->planar, t->lanes_per_view, true)) return CAMCAL_E_UNSUPPORTED;
   const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
   for (int i = 0; i < ng + ns; ++i) rec[i] = scratch[i];
   if (do_solve) {
@@ -538,7 +538,7 @@ int camcal_reduce_solve(int model, const camcal_tiles* t, double* scratch, doubl
 // the folded pinhole LM step of small sets: compositions of the stages
 static int small_pinhole(int model, const camcal_tiles* t) {
   if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
-  return (lanes_per_view_of(t->n_tiles, t->planar, t->lanes_per_view) <= 1 || model != 0) ? CAMCAL_E_UNSUPPORTED : 0;
+  return (model != 0 || !folded_set_of(t->n_tiles, t->planar, t->lanes_per_view, false)) ? CAMCAL_E_UNSUPPORTED : 0;
 }
 int camcal_small_set_begin(int model, const camcal_tiles* t, double* scratch, void*) {
   if (!t || !scratch) return CAMCAL_E_BADARG;
