@@ -1674,6 +1674,12 @@ int camcal_pose_predict_refine(int model, const camcal_tiles* tiles, const doubl
   return pose_refine_impl(model, tiles, intr, pose, max_iter, tol, iters, Y, dK, scale, cap, stream);
 }
 
+}  // extern "C"
+namespace {
+int normal_eq_fused_launch(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                           double* V, double* W, double* g, double* Y, double* scratch, void* stream);
+}
+extern "C" {
 // which sets run the folded stages: camcal_lane.h, folded_set_of (with the measurements behind the limits)
 static inline bool folded_set(const camcal_tiles* tiles, int model) {
   return folded_set_of(tiles->n_tiles, tiles->planar, tiles->lanes_per_view, model == CAMCAL_FISHEYE);
@@ -1695,12 +1701,24 @@ int camcal_refine_normal_eq_partial(int model, const camcal_tiles* tiles, const 
   if (predict && (!Y || !dK)) return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const int G = group_lanes(tiles);
-  if (model != CAMCAL_FISHEYE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;   // large sets: the stages on their own
+  if (model != CAMCAL_FISHEYE) return CAMCAL_E_UNSUPPORTED;
   const int np = tiles->n_tiles * G;
   const int rows = IntrAcc<FISHEYE>::NR + camcal_schur_len(CAMCAL_FISHEYE);
   unsigned* counter = first ? small_set_counter(tiles, G, rows, scratch) : nullptr;
   const dim3 gg(grid_groups(tiles, G)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
+  if (!folded_set(tiles, model)) {
+    // large sets: the re-estimation and the evaluation as launches of their own (each with its own register
+    // allocation and occupancy); what is shared with the small sets is that the evaluation stops at its partial
+    // records and camcal_reduce_solve does the rest in one launch
+    if (counter) HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned), s));
+    if (max_iter > 0) {
+      const int rc = pose_refine_impl(model, tiles, intr, pose, max_iter, tol, iters, predict ? Y : nullptr,
+                                      predict ? dK : nullptr, scale, cap, stream);
+      if (rc) return rc;
+    }
+    return normal_eq_fused_launch(model, tiles, intr, pose, 0.0, nullptr, nullptr, nullptr, Y, scratch, stream);
+  }
   if (G == 64) hipLaunchKernelGGL((k_refine_eval_grp<FISHEYE, 64>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, predict, dK, scale, cap, scratch, np, counter);
   else hipLaunchKernelGGL((k_refine_eval_grp<FISHEYE, 16>), gg, b, 0, s, *tiles, intr, pose, max_iter, tol, iters, Y, predict, dK, scale, cap, scratch, np, counter);
   HIP_TRY(hipGetLastError());
@@ -1714,8 +1732,8 @@ int camcal_reduce_solve(int model, const camcal_tiles* tiles, double* scratch, d
   if (do_solve && (!mask_host || !intr_in || !intr_out || !dK || !stats)) return CAMCAL_E_BADARG;
   if (model != CAMCAL_PINHOLE && model != CAMCAL_FISHEYE) return CAMCAL_E_BADMODEL;
   const int G = group_lanes(tiles);
-  if (model != CAMCAL_FISHEYE || !folded_set(tiles, model)) return CAMCAL_E_UNSUPPORTED;
-  const int np = tiles->n_tiles * G;
+  if (model != CAMCAL_FISHEYE) return CAMCAL_E_UNSUPPORTED;
+  const int np = tiles->n_tiles * G;                   // partial records: wavefronts of a grouped launch, else tiles
   const int rows = IntrAcc<FISHEYE>::NR + camcal_schur_len(CAMCAL_FISHEYE);
   unsigned mask = 0;
   if (do_solve)
@@ -1960,38 +1978,25 @@ int camcal_normal_eq(int model, const camcal_tiles* tiles, const double* intr, c
 namespace {
 // camcal_normal_eq_fused, optionally (Y != NULL; then no block stores and lam = 0) leaving the
 // views' first-order pose response for camcal_pose_predict
-int normal_eq_fused_impl(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
-                         double* V, double* W, double* g, double* Y, double* glob, double* schur, double* scratch,
-                         void* stream) {
-  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !schur || !scratch) return CAMCAL_E_BADARG;
-  const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
-  if (ng < 0) return ng;
+// the first stage of camcal_normal_eq_fused alone: the partial records [U|b|cost|C|d], one per wavefront (several
+// lanes per view) or per tile, row stride = their number
+int normal_eq_fused_launch(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                           double* V, double* W, double* g, double* Y, double* scratch, void* stream) {
   const bool wb = V && W && g;
-  if (!wb && (V || W || g)) return CAMCAL_E_BADARG;
-  if (Y && (wb || lam != 0.0)) return CAMCAL_E_BADARG;
-  if (schur != glob + ng) return CAMCAL_E_BADARG;
   const dim3 gr(grid_tiles(tiles)), b(TPB);
   hipStream_t s = (hipStream_t)stream;
   const int nt = tiles->n_tiles;
-  const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
   const int G = group_lanes(tiles);
   if (G > 1) {
     const int np = nt * G;                              // one partial record per wavefront
     const dim3 gg(grid_groups(tiles, G));
-    double* redg = scratch + (size_t)(nr + ns) * np;
 #define LAUNCHG(M, GG) hipLaunchKernelGGL((k_normal_fused_grp<M, GG>), gg, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, np, 0, Y)
     if (model == CAMCAL_PINHOLE) { if (G == 64) LAUNCHG(PINHOLE, 64); else LAUNCHG(PINHOLE, 16); }
     else { if (G == 64) LAUNCHG(FISHEYE, 64); else LAUNCHG(FISHEYE, 16); }
 #undef LAUNCHG
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_finalize_strided, dim3(nr + ns), dim3(TPB), 0, s, scratch, np, np, redg);
-    HIP_TRY(hipGetLastError());
-    if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, redg, glob, ns, 0);
-    else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, redg, glob, ns, 0);
-    HIP_TRY(hipGetLastError());
     return 0;
   }
-  double* red = scratch + (size_t)(nr + ns) * nt;
   if (wb) {
 #define LAUNCH(M, P) hipLaunchKernelGGL((k_normal_fused<M, true, P>), gr, b, 0, s, *tiles, intr, pose, lam, V, W, g, scratch, nt, nullptr)
     DISPATCH_MODEL_PLANAR(model, tiles->planar, LAUNCH);
@@ -2006,7 +2011,26 @@ int normal_eq_fused_impl(int model, const camcal_tiles* tiles, const double* int
 #undef LAUNCH
   }
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(k_finalize_strided, dim3(nr + ns), dim3(TPB), 0, s, scratch, nt, nt, red);
+  return 0;
+}
+
+int normal_eq_fused_impl(int model, const camcal_tiles* tiles, const double* intr, const double* pose, double lam,
+                         double* V, double* W, double* g, double* Y, double* glob, double* schur, double* scratch,
+                         void* stream) {
+  if (!tiles_ok(tiles) || !tiles->pts || !intr || !pose || !glob || !schur || !scratch) return CAMCAL_E_BADARG;
+  const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
+  if (ng < 0) return ng;
+  const bool wb = V && W && g;
+  if (!wb && (V || W || g)) return CAMCAL_E_BADARG;
+  if (Y && (wb || lam != 0.0)) return CAMCAL_E_BADARG;
+  if (schur != glob + ng) return CAMCAL_E_BADARG;
+  const int rc = normal_eq_fused_launch(model, tiles, intr, pose, lam, V, W, g, Y, scratch, stream);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int nr = model == CAMCAL_PINHOLE ? IntrAcc<PINHOLE>::NR : IntrAcc<FISHEYE>::NR;
+  const int np = tiles->n_tiles * group_lanes(tiles);   // partial records: wavefronts of a grouped launch, else tiles
+  double* red = scratch + (size_t)(nr + ns) * np;
+  hipLaunchKernelGGL(k_finalize_strided, dim3(nr + ns), dim3(TPB), 0, s, scratch, np, np, red);
   HIP_TRY(hipGetLastError());
   if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);
   else hipLaunchKernelGGL(k_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, glob, ns, 0);

@@ -242,9 +242,10 @@ int camcal_normal_eq_fused_static(int model, const camcal_tiles* tiles, const do
  * the five launches of an iteration into two.  A
  * production-sized iteration is a chain of ~5 ... 60 us kernels whose length is set by the one or two views
  * that need 18 - 20 Gauss-Newton steps; every launch boundary and every separate small kernel on that
- * chain is wall clock.  CAMCAL_E_UNSUPPORTED for other sets and for the pinhole model (callers then use
- * the stages above; camcal_fisheye_gn does).  NO COUNTERPART IN THE REFERENCE (cv2 runs the loop inside
- * cv::fisheye::calibrate, camera_calib.py:74-77).
+ * chain is wall clock.  Larger sets are accepted too: there the re-estimation and the evaluation remain
+ * launches of their own (three launches per iteration instead of five and a copy).  CAMCAL_E_UNSUPPORTED for
+ * the pinhole model.  NO COUNTERPART IN THE REFERENCE (cv2 runs the loop inside cv::fisheye::calibrate,
+ * camera_calib.py:74-77).
  *
  * camcal_refine_normal_eq_partial: camcal_pose_predict_refine (predict != 0; needs Y, dK) or
  * camcal_pose_refine (predict == 0), skipped altogether with max_iter == 0, followed IN THE SAME LAUNCH

@@ -506,7 +506,7 @@ int camcal_refine_normal_eq_partial(int model, const camcal_tiles* t, const doub
                                     int cap, int, double* scratch, void* s) {
   if (!t || !intr || !pose || !scratch || max_iter < 0 || (predict && (!Y || !dK))) return CAMCAL_E_BADARG;
   if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
-  if (model != 1 || !folded_set_of(t->n_tiles, t->planar, t->lanes_per_view, true)) return CAMCAL_E_UNSUPPORTED;
+  if (model != 1) return CAMCAL_E_UNSUPPORTED;
   if (max_iter > 0) {
     const int rc = predict ? camcal_pose_predict_refine(model, t, intr, Y, dK, scale, cap, pose, max_iter, tol, iters, s)
                            : camcal_pose_refine(model, t, intr, pose, max_iter, tol, iters, s);
@@ -521,7 +521,7 @@ int camcal_reduce_solve(int model, const camcal_tiles* t, double* scratch, doubl
                         double* notify, double seq, void* s) {
   if (!t || !scratch || !rec || (do_solve && (!mask_host || !intr_in || !intr_out || !dK || !stats))) return CAMCAL_E_BADARG;
   if (model != 0 && model != 1) return CAMCAL_E_BADMODEL;
-  if (model != 1 || !folded_set_of(t->n_tiles, t->planar, t->lanes_per_view, true)) return CAMCAL_E_UNSUPPORTED;
+  if (model != 1) return CAMCAL_E_UNSUPPORTED;
   const int ng = camcal_glob_len(model), ns = camcal_schur_len(model);
   for (int i = 0; i < ng + ns; ++i) rec[i] = scratch[i];
   if (do_solve) {

@@ -541,7 +541,8 @@ def case_two_launch_iteration_of_small_sets():
     launches per iteration) against the five separate stages: the same record, intrinsic step, poses and step
     counts, 16 and 64 lanes per view.  Same device functions, but inlined into different kernels (different
     multiply-add contraction): equal to 1e-12, not to the bit (the shared-call build, camcal_kernels.hip
-    CAMCAL_SHARED_CALL, is bit-identical); one lane per view is refused (the stages run then)."""
+    CAMCAL_SHARED_CALL, is bit-identical).  One lane per view (large sets): the re-estimation and the evaluation
+    stay launches of their own, only the second stage is shared; the pinhole model is refused."""
     from cameracalibration_amd import api, _lib
     from cameracalibration_amd.engine import Engine
     lib, dev = api._resolve()
@@ -551,7 +552,7 @@ def case_two_launch_iteration_of_small_sets():
 
     def close(x, y, tol=1e-12):
         return np.abs(x - y).max() <= tol * max(np.abs(x).max(), 1e-300)
-    for lpv in (16, 64):
+    for lpv in (16, 64, 1):            # one lane per view: the large-set form (separate launches, same second stage)
         A = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
         B = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=lpv)
         for E in (A, B):
@@ -581,12 +582,11 @@ def case_two_launch_iteration_of_small_sets():
         B.reduce_solve(mask, 0.0, 0.0, 0, 0, solve=False)
         assert close(A.rec.cpu().numpy()[:89], B.rec.cpu().numpy()[:89], 1e-11)
         del A, B
-    E = Engine(_lib.FISHEYE, P.view_ptr, P.obj, P.img, dev, lib=lib, lanes_per_view=1)
-    E.set_intr(0, g)
-    E.pose_init(0, 0)
+    Pp = synth.config("C1R", n_views=30)
+    E = Engine(_lib.PINHOLE, Pp.view_ptr, Pp.obj, Pp.img, dev, lib=lib)
     try:
         E.refine_normal_eq_partial(0, 0, max_iter=0, first=True)
-        raise AssertionError("one lane per view must be refused")
+        raise AssertionError("the pinhole model must be refused (its loop is CvLevMarq, not this one)")
     except _lib.CamcalStatus as exc:
         assert exc.code == _lib.E_UNSUPPORTED
 
