@@ -94,8 +94,13 @@ def _resolve():
     return None, _device()
 
 
-def _gather_views(object_points, image_points, min_points=4):
-    """cv2-style lists of (n_i,1,3)/(n_i,1,2) arrays -> CSR float32 arrays."""
+_NOT_PLANAR = ("only planar calibration targets with Z = 0 are supported "
+               "(the reference's chessboard / ChArUco boards)")
+
+
+def _gather_views(object_points, image_points, min_points=4, planar_check=True):
+    """cv2-style lists of (n_i,1,3)/(n_i,1,2) arrays -> CSR float32 arrays.  ``planar_check=False``: the caller
+    hands the arrays to camcal_calibrate, which makes that check itself (CAMCAL_E_UNSUPPORTED)."""
     try:
         nv = len(object_points)
         ni = len(image_points)
@@ -113,8 +118,8 @@ def _gather_views(object_points, image_points, min_points=4):
             # cheaper than .size over a list), else from the sizes
             if cat_o.ndim > 1 and cat_i.ndim > 1 and int(np.prod(cat_o.shape[1:])) == 3 \
                     and int(np.prod(cat_i.shape[1:])) == 2:
-                counts = np.array(list(map(len, object_points)), dtype=np.int64)
-                ci = np.array(list(map(len, image_points)), dtype=np.int64)
+                counts = np.fromiter(map(len, object_points), dtype=np.int64, count=nv)
+                ci = np.fromiter(map(len, image_points), dtype=np.int64, count=nv)
                 so, si = counts * 3, ci * 2
             else:
                 so = si = None
@@ -154,18 +159,17 @@ def _gather_views(object_points, image_points, min_points=4):
     view_ptr[1:] = np.cumsum(counts)
     obj = objs[0] if len(objs) == 1 else np.concatenate(objs, axis=0)
     img = imgs[0] if len(imgs) == 1 else np.concatenate(imgs, axis=0)
-    if obj[:, 2].any():
-        raise error("only planar calibration targets with Z = 0 are supported "
-                    "(the reference's chessboard / ChArUco boards)")
+    if planar_check and obj[:, 2].any():
+        raise error(_NOT_PLANAR)
     return view_ptr, obj, img
 
 
-def _gather_collectively(object_points, image_points, comm):
+def _gather_collectively(object_points, image_points, comm, planar_check=True):
     """_gather_views; in a multi-rank call a shard that is rejected (a view with three corners, mismatched
     lists) makes EVERY rank raise, not only the one that holds it -- the others would otherwise wait in the
     first collective of the solve for a rank that has left."""
     if not comm.enabled:
-        return _gather_views(object_points, image_points)
+        return _gather_views(object_points, image_points, planar_check=planar_check)
     exc = None
     try:
         out = _gather_views(object_points, image_points)
@@ -359,8 +363,8 @@ def _raise_status(rc, status, what):
                     "remove them" % (bad[:16].tolist(),))
     if rc == _lib.E_NUMERIC:
         raise error("the solve met a singular system or a non-finite cost (%s)" % what)
-    if rc == _lib.E_UNSUPPORTED:
-        raise error("%s: flag combination or target not supported" % what)
+    if rc == _lib.E_UNSUPPORTED:      # the flags were checked before the call: what the library refuses is the target
+        raise error(_NOT_PLANAR)
     raise _lib.CamcalStatus("%s failed with status %d" % (what, rc), rc)
 
 
@@ -456,7 +460,7 @@ def calibrate_many(calls):
             nd, mid = 4, _lib.FISHEYE
         else:
             raise error("model must be 'pinhole' or 'fisheye'")
-        view_ptr, obj, img = _gather_views(c["objectPoints"], c["imagePoints"])
+        view_ptr, obj, img = _gather_views(c["objectPoints"], c["imagePoints"], planar_check=False)
         K9 = _k9(intr0)
         p, ws, rt, status = _problem(lib, dev, mid, view_ptr, obj, img, c["imageSize"], K9, D5, nd, flags, crit, keep)
         items.append((c, model, p, ws, rt, status, K9, D5, D))
@@ -497,7 +501,9 @@ def calibrateCamera(objectPoints, imagePoints, imageSize, cameraMatrix, distCoef
     flags = int(flags)
     D, intr0, mask, maxc, eps = _prep_pinhole(imageSize, cameraMatrix, distCoeffs, flags, criteria)
     comm = _comm or _solver.Comm()
-    view_ptr, obj, img = _gather_collectively(objectPoints, imagePoints, comm)
+    # (the one-call path leaves the planarity check to the library)
+    view_ptr, obj, img = _gather_collectively(objectPoints, imagePoints, comm,
+                                              planar_check=not (_info is None and not comm.enabled))
     if _info is None and not comm.enabled:
         # the plain call: everything behind one library entry point (camcal_calibrate)
         rms, K9, D5, rt, _ = _one_call(_lib.PINHOLE, view_ptr, obj, img, imageSize, _k9(intr0), intr0[4:9].copy(), D.size,
@@ -579,7 +585,9 @@ def fisheye_calibrate(objectPoints, imagePoints, image_size, K, D, rvecs=None, t
     flags = int(flags)
     intr0, mask = _prep_fisheye(K, D, flags)
     comm = _comm or _solver.Comm()
-    view_ptr, obj, img = _gather_collectively(objectPoints, imagePoints, comm)
+    # (the one-call path leaves the planarity check to the library)
+    view_ptr, obj, img = _gather_collectively(objectPoints, imagePoints, comm,
+                                              planar_check=not (_info is None and not comm.enabled))
     if _info is None and not comm.enabled:
         D4 = np.asarray(D, dtype=np.float64).ravel().copy()
         rms, K9, D4, rt, _ = _one_call(_lib.FISHEYE, view_ptr, obj, img, image_size, _k9(intr0), D4, 4, flags, criteria)
