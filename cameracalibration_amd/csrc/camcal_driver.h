@@ -61,7 +61,7 @@ struct FisheyeGN {
   double change = 1.0, cost = 0.0;
   int it = 0;
   bool refine_first = false;            // the caller's poses come straight from the initialisation: refine them first
-  int fused = -1;                       // small sets: two launches per iteration (-1: not tried yet, 0: no)
+  int fused = -1;                       // one rank: two / three launches per iteration (-1: not tried yet, 0: no)
   bool have_partials = false;           // an evaluation at the current point waits in scratch
   double seq = 0.0;                     // > 0: the scalars of this step come through the reader's notify buffer
   enum { READY, ITERATION, FINAL_COST, DONE } pending = READY;
@@ -77,9 +77,10 @@ struct FisheyeGN {
     const bool stop = (crit_type == 1 && it >= max_count) || (crit_type == 2 && change <= eps) ||
                       (crit_type == 3 && (change <= eps || it >= max_count));
     if (fused != 0 && !comm) {
-      // Small set: [sum + solve] and [re-estimation + the NEXT evaluation] are one launch each
-      // (camcal_reduce_solve, camcal_refine_normal_eq_partial).  The evaluation at the point the loop
-      // stops at has then been made already: its cost is the result's, no pass of its own.
+      // One rank: [sum + solve] is one launch (camcal_reduce_solve) and [re-estimation + the NEXT evaluation]
+      // one (small sets) or two (camcal_refine_normal_eq_partial); the scalars come through the notify buffer.
+      // The evaluation at the point the loop stops at has then been made already: its cost is the result's,
+      // no pass of its own.
       const bool respond = Y && recompute_extrinsic;
       if (!have_partials) {              // (with refine_first: the first refinement rides along)
         const int rc = camcal_refine_normal_eq_partial(CAMCAL_FISHEYE, tiles, intr, pose, refine_first ? 20 : 0, 1e-10, iters,

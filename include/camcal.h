@@ -352,10 +352,10 @@ int camcal_comm_allreduce(const camcal_comm* comm, double* buf, int64_t n, void*
  * instead of the previous one -- same results to the refinement's tolerance, about a third
  * fewer Gauss-Newton steps per view.
  * cost_out_host = sum of squared residuals at the result.
- * Single-rank calls on small sets run each iteration as camcal_reduce_solve +
- * camcal_refine_normal_eq_partial (two launches instead of five; the cost at the result comes from
- * the last evaluation instead of a pass of its own, so it can differ from the staged loop's in the
- * last bits of the sum; K, D, poses are identical); rec then holds the evaluation AT the result. */
+ * Single-rank calls run each iteration as camcal_reduce_solve + camcal_refine_normal_eq_partial (two
+ * launches instead of five on small sets, three on large ones; the cost at the result comes from the
+ * last evaluation instead of a pass of its own, so it can differ from the staged loop's in the last
+ * bits of the sum); rec then holds the evaluation AT the result. */
 int camcal_fisheye_gn(const camcal_tiles* tiles, double* intr, double* pose, const uint8_t* mask_host,
                       int crit_type, int max_count, double eps, int recompute_extrinsic, double* rec,
                       double* dK, double* stats, int32_t* iters, double* Y, double* scratch,
