@@ -112,6 +112,7 @@ _SIGNATURES = {
     "camcal_rig_scratch_len": (C.c_int64, [_I, _I, _P, C.c_int64]),
     "camcal_rig_evaluate": (C.c_int, [_P, _I, _P]),
     "camcal_rig_residuals": (C.c_int, [_P, _I, _P]),
+    "camcal_rig_residuals_notify": (C.c_int, [_P, _I, _P, C.c_double, _P]),
     "camcal_rig_chain": (C.c_int, [_P, _I, _P]),
     "camcal_rig_eliminate": (C.c_int, [_P, _I, _D, _P]),
     "camcal_rig_solve": (C.c_int, [_P, _I, C.c_char_p, _D, _I, _P]),

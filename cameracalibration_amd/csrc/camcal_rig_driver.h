@@ -92,6 +92,8 @@ int camcal_rig_lm(const camcal_rig* rig, const uint8_t* mask_host, int max_iter,
     double back[5] = {0, 0, 0, 0, 0};              // cost | norms (2) | gstats (2) of the trial point
     for (;;) {
       const double lam = std::pow(10.0, (double)lam_lg10);
+      double* note = nullptr;
+      double seq = 0.0;
       CAMCAL_DRV_TRY(camcal_rig_eliminate(rig, cur, lam, stream));
       CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rig->rec[cur] + L.o_C, (int64_t)L.n * L.n + L.n, stream));
       CAMCAL_DRV_TRY(camcal_rig_solve(rig, cur, mask_host, lam, tri, stream));
@@ -102,12 +104,17 @@ int camcal_rig_lm(const camcal_rig* rig, const uint8_t* mask_host, int max_iter,
         CAMCAL_DRV_TRY(camcal_comm_allreduce(comm, rig->rec[tri], L.o_gstats, stream));
         CAMCAL_DRV_TRY(rd.begin(rig->rec[tri] + L.o_cost, 5, 0, stream));
       } else {
-        // one process: the cost travels to the host while the chain rule of the trial point runs
-        CAMCAL_DRV_TRY(camcal_rig_residuals(rig, tri, stream));
-        CAMCAL_DRV_TRY(rd.begin(rig->rec[tri] + L.o_cost, 5, 0, stream));
+        // one process: the cost travels to the host while the chain rule of the trial point runs -- written by
+        // the residual stage's last kernel into the reader's pinned buffer where that is mapped (no copy between
+        // the stage and the chain rule), else by a copy
+        note = rd.notify(&seq);
+        if (!note) seq = 0.0;
+        CAMCAL_DRV_TRY(camcal_rig_residuals_notify(rig, tri, note, seq, stream));
+        if (!note) CAMCAL_DRV_TRY(rd.begin(rig->rec[tri] + L.o_cost, 5, 0, stream));
         CAMCAL_DRV_TRY(camcal_rig_chain(rig, tri, stream));
       }
-      CAMCAL_DRV_TRY(rd.end(back, 5));
+      if (note) CAMCAL_DRV_TRY(rd.wait(seq, stream, back, 5));
+      else CAMCAL_DRV_TRY(rd.end(back, 5));
       err = back[0];
       if (err <= prev_err) break;                  // NaN (failed factorisation) rejects the step
       ++lam_lg10;

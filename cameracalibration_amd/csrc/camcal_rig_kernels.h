@@ -126,8 +126,8 @@ __global__ __launch_bounds__(TPB) void k_rig_finalize(const double* __restrict__
 
 // reduced accumulator values of every camera -> its [U|b|cost] record; then the rig's cost
 template <int MODEL>
-__global__ __launch_bounds__(64) void k_rig_expand(const double* __restrict__ red, int n_cams, double* __restrict__ rec,
-                                                   int per, int o_cost) {
+__global__ __launch_bounds__(64) void k_rig_expand(const double* __restrict__ red, int n_cams, double* rec,
+                                                   int per, int o_cost, double* notify, double seq) {
   constexpr int NR = IntrAcc<MODEL>::NR, NV = IntrAcc<MODEL>::NV;
   __shared__ double cost[CAMCAL_RIG_MAX_CAMS];
   const int c = threadIdx.x;
@@ -143,6 +143,15 @@ __global__ __launch_bounds__(64) void k_rig_expand(const double* __restrict__ re
     double s = 0.0;
     for (int k = 0; k < n_cams; ++k) s += cost[k];
     rec[o_cost] = s;
+    // the LM loop's five scalars [cost | pose-step norms (2) | intrinsic-step norms (2)] straight to the host's
+    // pinned landing buffer, sequence number last (the norms were left in the record by the solve and the
+    // back-substitution of this trial point, earlier launches on the stream)
+    if (notify) {
+      notify[0] = s;
+      for (int k = 1; k < 5; ++k) notify[k] = rec[o_cost + k];
+      __threadfence_system();
+      __hip_atomic_store(&notify[CAMCAL_NOTIFY_SEQ], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -755,6 +764,10 @@ int64_t camcal_rig_scratch_len(int model, int n_cams, const int32_t* n_tiles_hos
 }
 
 int camcal_rig_residuals(const camcal_rig* rig, int b, void* stream) {
+  return camcal_rig_residuals_notify(rig, b, nullptr, 0.0, stream);
+}
+
+int camcal_rig_residuals_notify(const camcal_rig* rig, int b, double* notify, double seq, void* stream) {
   if (!rig_ok(rig) || (b != 0 && b != 1)) return CAMCAL_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const int nC = rig->n_cams, model = rig->model;
@@ -789,8 +802,8 @@ int camcal_rig_residuals(const camcal_rig* rig, int b, void* stream) {
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(k_rig_finalize, dim3(nr, nC), bl, 0, s, rig->scratch, parts, red, nr);
   HIP_TRY(hipGetLastError());
-  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_rig_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, nC, rig->rec[b], L.per, L.o_cost);
-  else hipLaunchKernelGGL(k_rig_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, nC, rig->rec[b], L.per, L.o_cost);
+  if (model == CAMCAL_PINHOLE) hipLaunchKernelGGL(k_rig_expand<PINHOLE>, dim3(1), dim3(64), 0, s, red, nC, rig->rec[b], L.per, L.o_cost, notify, seq);
+  else hipLaunchKernelGGL(k_rig_expand<FISHEYE>, dim3(1), dim3(64), 0, s, red, nC, rig->rec[b], L.per, L.o_cost, notify, seq);
   HIP_TRY(hipGetLastError());
   return 0;
 }

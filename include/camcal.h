@@ -515,6 +515,11 @@ int camcal_rig_evaluate(const camcal_rig* rig, int b, void* stream);
  * -> Vp/gp/Wp[b] and the extrinsic records of rec[b].  evaluate = residuals, then chain. */
 int camcal_rig_residuals(const camcal_rig* rig, int b, void* stream);
 int camcal_rig_chain(const camcal_rig* rig, int b, void* stream);
+/* camcal_rig_residuals that also hands the LM loop's five scalars of rec[b] -- [cost | pose-step norms (2) |
+ * intrinsic-step norms (2)], the last four as the solve and the back-substitution of this trial point left them
+ * -- to the host without a copy on the stream: notify = device-visible address of 16 pinned, coherent doubles
+ * (see camcal_reduce_solve), sequence number written last at CAMCAL_NOTIFY_SEQ. */
+int camcal_rig_residuals_notify(const camcal_rig* rig, int b, double* notify, double seq, void* stream);
 
 /* Pose elimination at damping lam: per board pose V = sum_c Vp_c (diag*(1+lam)) = U^T U,
  * Yt = U^-T Wp^T, z = U^-T g; then C = Y^T Y and d = Y^T z on the matrix cores

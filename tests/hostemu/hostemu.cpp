@@ -633,6 +633,14 @@ int camcal_rig_residuals(const camcal_rig* rg, int b, void*) {
   rg->rec[b][L.o_cost] = cost;
   return 0;
 }
+int camcal_rig_residuals_notify(const camcal_rig* rg, int b, double* notify, double seq, void* stream) {
+  const int rc = camcal_rig_residuals(rg, b, stream);
+  if (rc || !notify) return rc;
+  const camcal::RigLayout L(camcal_n_intr(rg->model), rg->n_cams);
+  for (int k = 0; k < 5; ++k) notify[k] = rg->rec[b][L.o_cost + k];
+  notify[CAMCAL_NOTIFY_SEQ] = seq;
+  return 0;
+}
 int camcal_rig_chain(const camcal_rig* rg, int b, void*) {
   const RigLayout L(camcal_n_intr(rg->model), rg->n_cams);
   for (int c = 0; c < rg->n_cams; ++c) {
