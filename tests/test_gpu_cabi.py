@@ -59,3 +59,14 @@ def test_one_call_entry_on_its_fallback_transfer_paths(tmp_path):
         res[tag] = np.load(f)
     for tag in ("direct", "copies", "both"):
         assert np.array_equal(res[tag], res["default"]), tag
+
+
+@pytest.mark.gpu
+def test_randomised_small_calls_one_call_path_equals_the_stage_loop():
+    """tools/gpu_fuzz_small.py: 80 random production-sized calls (view counts 4 ... 300, ragged corner counts, random FIX_*
+    flags and iteration caps, both models) through the one-call path (folded loops, run-ahead half step, notify buffer)
+    against the stage-by-stage Python loop: rms and K to 1e-8 relative, rotation vectors to 1e-6."""
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz_small.py"), "11", "80"],
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0
