@@ -676,6 +676,45 @@ def case_pinhole_lm_with_rejected_steps():
 ALL.append(case_pinhole_lm_with_rejected_steps)
 
 
+def case_randomised_production_sized_calls_vs_oracle():
+    """24 random production-sized calls (4 ... 40 views, full and ragged boards, random FIX_* flag sets, iteration caps
+    1 ... 1000, both models) through the plain drop-in call -- the one-call path with its folded loops -- against the
+    cv2-faithful oracle (dense CvLevMarq / Schur-eliminated fisheye loop): rms to 1e-9 px, K to 1e-8, D to 1e-6
+    relative and the poses for runs that may converge (caps >= 100); 1e-7 / 1e-6 / 1e-4 for runs cut short."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        fisheye = case % 2 == 0
+        nv = int(rng.choice([4, 6, 9, 15, 25, 40]))
+        name = ("C3" if rng.integers(2) else "C2") if fisheye else ("C1R" if rng.integers(2) else "C1")
+        P = synth.config(name, n_views=nv, seed=int(rng.integers(1 << 30)))
+        objs, imgs = P.as_lists()
+        crit = (3, int(rng.choice([1, 3, 10, 100, 1000])), 1e-6)
+        if fisheye:
+            fl = FE
+            for bit in (16, 32, 64, 128, 512, 2048):             # FIX_K1..K4, FIX_PRINCIPAL_POINT, FIX_FOCAL_LENGTH
+                if rng.integers(6) == 0:
+                    fl |= bit
+            r = cc.fisheye.calibrate(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit)
+            o = O.fisheye_calibrate(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=fl, criteria=crit, solver="schur")
+            assert np.allclose(np.hstack(r[3]).T, o[3], atol=1e-7) and np.allclose(np.hstack(r[4]).T, o[4], atol=1e-5), (case, fl)
+        else:
+            fl = 1
+            for bit in (4, 8, 16, 32, 64, 128):                  # FIX_PRINCIPAL_POINT, ZERO_TANGENT, FIX_FOCAL, FIX_K1..K3
+                if rng.integers(6) == 0:
+                    fl |= bit
+            r = cc.calibrateCamera(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit)
+            o = O.calibrate_camera(objs, imgs, P.image_size, P.K_guess, P.D_guess, flags=fl, criteria=crit, solver="dense")
+        # a run stopped by a small iteration cap is not at a fixed point: what the two implementations' starting poses
+        # differ by (each refined to cv2's 1e-10 rule, not to the bit) has not been contracted away yet
+        loose = crit[1] < 100
+        assert abs(r[0] - o[0]) < (1e-7 if loose else 1e-9), (case, name, nv, fl, crit, r[0], o[0])
+        assert np.allclose(r[1], o[1], rtol=1e-6 if loose else 1e-8, atol=0), (case, name, nv, fl, crit)
+        assert np.allclose(np.asarray(r[2]).ravel(), np.asarray(o[2]).ravel(), rtol=1e-4 if loose else 1e-6, atol=1e-9), (case, name, nv, fl, crit)
+
+
+ALL.append(case_randomised_production_sized_calls_vs_oracle)
+
+
 def case_one_call_entry_and_calibrate_many():
     """camcal_calibrate (what the plain drop-in call runs) against the stage-by-stage Engine path (chosen by
     passing _info), bit for bit; camcal_calibrate_many on the reference's four-camera loop (cali_in:
