@@ -609,9 +609,8 @@ __device__ __forceinline__ bool group_view(const camcal_tiles& t, GroupView& gv)
 }
 
 // the Gauss-Newton loop of one view shared by the G lanes of its group (max_iter > 0); returns the steps taken
-// (A real call, not inlined: k_pose_refine_grp and k_refine_eval_grp then run the SAME machine code, so the
-// fused launch returns the separate stages' bits -- inlined into different kernels the compiler contracts
-// different multiply-adds.  Likewise group_normal_fused.)
+// (Shared by k_pose_refine_grp and k_refine_eval_grp -- inlined into each unless CAMCAL_SHARED_CALL says
+// otherwise, see the note at its definition.  Likewise group_normal_fused.)
 template <int MODEL, int G>
 __device__ CAMCAL_SHARED_CALL int group_pose_refine(const GroupView& gvr, const double* Ip, double qp[6], int max_iter, double tol) {
   constexpr int NI = MT<MODEL>::NI;
@@ -766,7 +765,7 @@ __global__ __launch_bounds__(TPB) void k_normal_fused_grp(camcal_tiles t, const 
 // slowest view (C2: one or two views run to 18 - 20 steps in each of the first four iterations
 // while the mean is 3 - 4); evaluated in the same launch, the other views' records are done long
 // before the slowest view has converged, and a kernel boundary and the evaluation's own ramp
-// disappear from every iteration.  Same device functions, same bits as the two launches.
+// disappear from every iteration.  Same device functions as the two launches (equal to ~1e-13, see CAMCAL_SHARED_CALL).
 // Leaves the partial records in scratch (k_reduce_solve sums them).
 template <int MODEL, int G>
 __global__ __launch_bounds__(TPB) void k_refine_eval_grp(camcal_tiles t, const double* __restrict__ intr,
