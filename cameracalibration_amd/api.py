@@ -109,7 +109,18 @@ def _gather_views(object_points, image_points, min_points=4, planar_check=True):
     if nv == 0 or nv != ni:
         raise error("objectPoints and imagePoints must be non-empty and of equal length "
                     "(nimages > 0 && nimages == (int)imagePoints.total())")
-    if set(map(type, object_points)) == {np.ndarray} and set(map(type, image_points)) == {np.ndarray}:
+    if isinstance(object_points, np.ndarray) and isinstance(image_points, np.ndarray) \
+            and object_points.ndim >= 3 and image_points.ndim >= 3 \
+            and object_points[0].size % 3 == 0 and image_points[0].size % 2 == 0 \
+            and object_points[0].size // 3 == image_points[0].size // 2:
+        # views stacked in one array each ((N,n,1,3) / (N,n,1,2) or (N,n,3) / (N,n,2)): equal counts, no gathering
+        n = object_points[0].size // 3
+        if n < min_points:
+            raise error("every view needs at least %d points" % min_points)
+        counts = np.full(nv, n, dtype=np.int64)
+        objs = [np.ascontiguousarray(object_points, dtype=np.float32).reshape(-1, 3)]
+        imgs = [np.ascontiguousarray(image_points, dtype=np.float32).reshape(-1, 2)]
+    elif set(map(type, object_points)) == {np.ndarray} and set(map(type, image_points)) == {np.ndarray}:
         # the usual call: lists of ndarrays -- one concatenation each, no per-view conversions
         try:                                   # equal trailing shapes ((n,1,3) / (n,3)): one C call each
             cat_o = np.concatenate(object_points, axis=0)

@@ -172,6 +172,17 @@ def test_view_lists_in_any_array_form():
     for fo, fi in forms:
         vp2, o2, i2 = _gather_views(fo, fi)
         assert np.array_equal(vp, vp2) and np.array_equal(o, o2) and np.array_equal(i, i2)
+    # every view of one size, stacked into one array each: no per-view work at all
+    Q = synth.config("C2", n_views=12)
+    qo, qi = Q.as_lists()
+    ref = _gather_views(qo, qi)
+    for so, si in ((np.stack(qo), np.stack(qi)), (np.stack(qo).reshape(12, -1, 3).astype(np.float64), np.stack(qi).reshape(12, -1, 2))):
+        got = _gather_views(so, si)
+        assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(ref, got))
+    with pytest.raises(cc.error):
+        _gather_views(np.stack(qo)[:, :3], np.stack(qi)[:, :3])
+    with pytest.raises(cc.error):
+        _gather_views(np.stack(qo), np.stack(qi)[:, :-1])
     for fo, fi in ((objs, imgs), ([x.tolist() for x in objs], [x.tolist() for x in imgs])):
         short = list(fi)
         short[3] = short[3][:-1]
