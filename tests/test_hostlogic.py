@@ -192,6 +192,17 @@ def test_view_lists_in_any_array_form():
             _gather_views([x[:3] for x in fo], [x[:3] for x in fi])      # fewer than 4 points per view
 
 
+def test_stacked_views_through_the_drop_in_calls(emu):
+    """(N,n,1,3) / (N,n,1,2) arrays instead of lists: the same calibration, bit for bit."""
+    for name, call, flags in (("C1", cc.calibrateCamera, cc.CALIB_USE_INTRINSIC_GUESS), ("C2", cc.fisheye.calibrate, FE)):
+        P = synth.config(name, n_views=16)
+        objs, imgs = P.as_lists()
+        a = call(objs, imgs, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=flags, criteria=CRIT)
+        b = call(np.stack(objs), np.stack(imgs), P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=flags, criteria=CRIT)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert len(b[3]) == 16 and np.array_equal(np.hstack(a[3]), np.hstack(b[3])) and np.array_equal(np.hstack(a[4]), np.hstack(b[4]))
+
+
 def test_errors_like_cv2(emu):
     P = synth.config("C1")
     objs, imgs = P.as_lists()
