@@ -11,8 +11,8 @@ all: lib hostemu oracle examples
 
 lib: $(CSRC)/libcamcal.so
 CSRC_HDRS := $(wildcard $(CSRC)/*.h) include/camcal.h
-$(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC_HDRS)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS_EXTRA) $< -o $@
+$(CSRC)/libcamcal.so: $(CSRC)/camcal_kernels.hip $(CSRC)/camcal_layout.hip $(CSRC_HDRS)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS_EXTRA) $(CSRC)/camcal_kernels.hip $(CSRC)/camcal_layout.hip -o $@
 
 hostemu: tests/hostemu/libcamcal_hostemu.so
 tests/hostemu/libcamcal_hostemu.so: tests/hostemu/hostemu.cpp $(CSRC_HDRS)

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "csrc", "libcamcal.so")
 
 PINHOLE, FISHEYE = 0, 1
+LAYOUT_NOT_PLANAR, LAYOUT_BAD_COUNT, LAYOUT_BAD_TOTAL = 1, 2, 4     # camcal_layout_device: head[2]
 
 
 class Tiles(C.Structure):
@@ -70,6 +71,8 @@ _SIGNATURES = {
     "camcal_schur_len": (C.c_int, [_I]),
     "camcal_scratch_len": (C.c_int64, [_I, _I]),
     "camcal_layout": (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "camcal_layout_device_temp_len": (C.c_int64, [C.c_int64]),
+    "camcal_layout_device": (C.c_int, [C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "camcal_pack_tiles": (C.c_int, [_P, _P, _P, _P, _TP, _P, _P]),
     "camcal_pose_init": (C.c_int, [_I, _TP, _P, _P, _P, _P]),
     "camcal_pose_refine": (C.c_int, [_I, _TP, _P, _P, _I, _D, _P, _P]),

@@ -1575,11 +1575,27 @@ int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, 
   *n_tiles = (int32_t)T;
   *n_slots = T * LANES;
   std::vector<int32_t> order((size_t)n_views);
+  int32_t top = 0;
   for (int64_t i = 0; i < n_views; ++i) {
     if (n_per_view[i] < 0) return CAMCAL_E_BADARG;
-    order[(size_t)i] = (int32_t)i;
+    top = n_per_view[i] > top ? n_per_view[i] : top;
   }
-  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_per_view[a] > n_per_view[b]; });
+  if (top <= (1 << 22)) {
+    // counting sort by descending count, views of one count in their own order (1M ragged views: 200 ms of
+    // std::stable_sort through the comparator, 6 ms this way -- and the solve on the device takes 37)
+    std::vector<int64_t> first((size_t)top + 2, 0);
+    for (int64_t i = 0; i < n_views; ++i) ++first[(size_t)n_per_view[i]];
+    int64_t at = 0;
+    for (int64_t c = top; c >= 0; --c) {
+      const int64_t k = first[(size_t)c];
+      first[(size_t)c] = at;
+      at += k;
+    }
+    for (int64_t i = 0; i < n_views; ++i) order[(size_t)first[(size_t)n_per_view[i]]++] = (int32_t)i;
+  } else {
+    for (int64_t i = 0; i < n_views; ++i) order[(size_t)i] = (int32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_per_view[a] > n_per_view[b]; });
+  }
   int64_t off = 0;
   for (int64_t t = 0; t < T; ++t) {
     int32_t nmax = 0;

@@ -96,26 +96,36 @@ class Engine:
         dev = self.device
         lpv = int(self.LANES_PER_VIEW if lanes_per_view is None else lanes_per_view)
         n_views = int(len(view_ptr)) - 1
+        t_obj = t_img = None
         if dev.type == "cuda" and n_views >= self.DEVICE_LAYOUT_MIN_VIEWS:
-            # large sets: the sort and the prefix sums of the layout run on the device (the same
-            # tables as make_layout; 1M views cost 10-15 ms in numpy, more than a third of a whole
-            # C5 solve); the host copy of the tables is only made when a caller asks for it
-            t_vp = torch.as_tensor(view_ptr).to(device=dev, dtype=torch.int64)
-            n = t_vp[1:] - t_vp[:-1]
+            # large sets: camcal_layout_device -- the sort and the prefix sums of the layout run on the device (the
+            # same tables as make_layout; 1M views cost 10-15 ms in numpy, more than a third of a whole C5 solve),
+            # offsets and points are checked there too, and one read-back brings the sizes and the flags; the
+            # host copy of the tables is only made when a caller asks for it
+            t_vp = torch.as_tensor(view_ptr).to(device=dev, dtype=torch.int64).contiguous()
+            t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+            t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
             self.n_views = n_views
             T = max((n_views + LANES - 1) // LANES, 1)
             S = T * LANES
-            order = torch.argsort(n, descending=True, stable=True)
-            self.t_slot_view = torch.full((S,), -1, dtype=torch.int32, device=dev)
-            self.t_slot_view[:n_views] = order.to(torch.int32)
-            self.t_lane_n = torch.zeros(S, dtype=torch.int32, device=dev)
-            self.t_lane_n[:n_views] = n[order].to(torch.int32)
-            self.t_tile_nmax = self.t_lane_n.view(T, LANES).amax(dim=1)
-            sizes = self.t_tile_nmax.to(torch.int64) * (5 * LANES)
-            csum = torch.cumsum(sizes, 0)
-            self.t_tile_off = csum - sizes
-            head = torch.stack([t_vp[-1], csum[-1]]).cpu()          # the one read-back: n_obs, packed floats
-            self.n_obs, total_floats = int(head[0]), int(head[1])
+            tab = torch.empty(2 * T + 2 * 4 + 2 * S + T, dtype=torch.int32, device=dev)    # int64 tables first: alignment
+            self.t_tile_off = tab[:2 * T].view(torch.int64)
+            head = tab[2 * T:2 * T + 8].view(torch.int64)
+            o = 2 * T + 8
+            self.t_slot_view, self.t_lane_n, self.t_tile_nmax = tab[o:o + S], tab[o + S:o + 2 * S], tab[o + 2 * S:]
+            tmp_len = int(self.lib.camcal_layout_device_temp_len(n_views))
+            if tmp_len < 0:
+                self.lib.check(tmp_len, "camcal_layout_device_temp_len")
+            tmp = torch.empty(tmp_len, dtype=torch.uint8, device=dev)
+            self._call("camcal_layout_device", n_views, t_vp.data_ptr(), int(t_obj.shape[0]), t_obj.data_ptr(),
+                       self.t_slot_view.data_ptr(), self.t_lane_n.data_ptr(), self.t_tile_nmax.data_ptr(),
+                       self.t_tile_off.data_ptr(), head.data_ptr(), tmp.data_ptr(), tmp_len, self._stream())
+            h = head.cpu()                                          # the one read-back: n_obs, packed floats, flags
+            del tmp
+            self.n_obs, total_floats, flags = int(h[0]), int(h[1]), int(h[2])
+            if flags & (_lib.LAYOUT_BAD_COUNT | _lib.LAYOUT_BAD_TOTAL) or t_img.shape[0] != t_obj.shape[0]:
+                raise ValueError("view_ptr does not match the point arrays")
+            planar = not flags & _lib.LAYOUT_NOT_PLANAR
             self._layout = None
             lay = dict(n_tiles=T, n_slots=S, total_floats=total_floats)
         else:
@@ -142,16 +152,17 @@ class Engine:
                                 self.t_tile_nmax.data_ptr(), self.t_lane_n.data_ptr(),
                                 lay["n_tiles"], S, 0, lpv)
         # pack on the device
-        if isinstance(obj, np.ndarray):                     # host arrays: no device round trip for the flag
-            planar = not np.asarray(obj).reshape(-1, 3)[:, 2].any()
-            t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
-        else:
-            t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
-            planar = bool((t_obj[:, 2] == 0).all().item())
+        if t_obj is None:
+            if isinstance(obj, np.ndarray):                     # host arrays: no device round trip for the flag
+                planar = not np.asarray(obj).reshape(-1, 3)[:, 2].any()
+                t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+            else:
+                t_obj = torch.as_tensor(obj, dtype=torch.float32).reshape(-1, 3).contiguous().to(dev)
+                planar = bool((t_obj[:, 2] == 0).all().item())
+            t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
+            if t_obj.shape[0] != self.n_obs or t_img.shape[0] != self.n_obs:
+                raise ValueError("view_ptr does not match the point arrays")
         self.tiles.planar = 1 if planar else 0
-        t_img = torch.as_tensor(img, dtype=torch.float32).reshape(-1, 2).contiguous().to(dev)
-        if t_obj.shape[0] != self.n_obs or t_img.shape[0] != self.n_obs:
-            raise ValueError("view_ptr does not match the point arrays")
         self._call("camcal_pack_tiles", t_obj.data_ptr(), t_img.data_ptr(), t_vp.data_ptr(),
                    self.t_slot_view.data_ptr(), C.byref(self.tiles), self.t_pts.data_ptr(), self._stream())
         del t_obj, t_img, t_vp        # stream-ordered: the allocator reuses them only behind the pack

@@ -100,6 +100,29 @@ int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, 
                   int64_t* total_floats, int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax,
                   int64_t* tile_off);
 
+/* camcal_layout on the device, for sets whose CSR offsets and points are already there (no host
+ * pass over the views, nothing to upload): the same four tables, bit for bit, written to DEVICE arrays
+ * slot_view [n_slots], lane_n [n_slots], tile_nmax [n_tiles], tile_off [n_tiles] with n_tiles =
+ * max(ceil(n_views / 64), 1), n_slots = 64 n_tiles (known to the caller without asking).  view_ptr
+ * [n_views + 1] i64 (device), n_obs = the number of points the caller's arrays hold, obj_xyz
+ * [n_obs][3] f32 (device; NULL: no planarity test).  head: 4 x i64 in DEVICE memory, written by the
+ * call -- read it back (one copy, after the stream has passed the call) before anything is packed:
+ *   head[0] = view_ptr[n_views] - view_ptr[0]     head[1] = total_floats (length of pts)
+ *   head[2] = flags: CAMCAL_LAYOUT_NOT_PLANAR (some Z != 0), CAMCAL_LAYOUT_BAD_COUNT (a view with a
+ *             negative or >= 2^31 count), CAMCAL_LAYOUT_BAD_TOTAL (the offsets do not start at 0 or do not
+ *             end at n_obs) -- with either BAD flag set the tables must not be used
+ *   head[3] = the largest count of a view
+ * temp: camcal_layout_device_temp_len(n_views) bytes of device memory (sort keys + the sort's own
+ * storage), free again once the stream has passed the call.  Everything is stream-ordered; the call
+ * does not synchronise and allocates nothing.  No reference counterpart (as camcal_layout). */
+#define CAMCAL_LAYOUT_NOT_PLANAR 1
+#define CAMCAL_LAYOUT_BAD_COUNT 2
+#define CAMCAL_LAYOUT_BAD_TOTAL 4
+int64_t camcal_layout_device_temp_len(int64_t n_views);
+int camcal_layout_device(int64_t n_views, const int64_t* view_ptr, int64_t n_obs, const float* obj_xyz,
+                         int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off,
+                         int64_t* head, void* temp, int64_t temp_bytes, void* stream);
+
 /* Gather cv2-style AoS points into tiles.  obj_xyz [n_obs][3] f32, img_uv
  * [n_obs][2] f32, view_ptr [n_views+1] i64 (CSR), slot_view [n_slots] i32 =
  * view index placed in each slot or -1.  Writes tiles->pts (caller-allocated,

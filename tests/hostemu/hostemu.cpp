@@ -387,6 +387,33 @@ int camcal_layout(int64_t n_views, const int32_t* n_per_view, int32_t* n_tiles, 
   return 0;
 }
 
+// camcal_layout_device on host arrays: the counts from the offsets, then camcal_layout
+int64_t camcal_layout_device_temp_len(int64_t n_views) { return n_views < 0 ? CAMCAL_E_TOOBIG : 256; }
+int camcal_layout_device(int64_t n_views, const int64_t* view_ptr, int64_t n_obs, const float* obj_xyz,
+                         int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off,
+                         int64_t* head, void*, int64_t, void*) {
+  if (n_views < 0 || n_obs < 0 || !view_ptr || !slot_view || !lane_n || !tile_nmax || !tile_off || !head) return CAMCAL_E_BADARG;
+  std::vector<int32_t> n((size_t)n_views);
+  int64_t flags = 0;
+  for (int64_t i = 0; i < n_views; ++i) {
+    const int64_t c = view_ptr[i + 1] - view_ptr[i];
+    const bool bad = c < 0 || c > 2147483647LL;
+    if (bad) flags |= CAMCAL_LAYOUT_BAD_COUNT;
+    n[(size_t)i] = bad ? 0 : (int32_t)c;
+  }
+  const int64_t total = view_ptr[n_views] - view_ptr[0];
+  if (total != n_obs || view_ptr[0] != 0) flags |= CAMCAL_LAYOUT_BAD_TOTAL;
+  if (obj_xyz)
+    for (int64_t i = 0; i < n_obs; ++i)
+      if (!(obj_xyz[3 * i + 2] == 0.0f)) { flags |= CAMCAL_LAYOUT_NOT_PLANAR; break; }
+  int32_t nt = 0;
+  int64_t ns = 0, tf = 0;
+  const int rc = camcal_layout(n_views, n.data(), &nt, &ns, &tf, slot_view, lane_n, tile_nmax, tile_off);
+  if (rc) return rc;
+  head[0] = total; head[1] = tf; head[2] = flags; head[3] = n_views > 0 ? lane_n[0] : 0;
+  return 0;
+}
+
 int camcal_pack_tiles(const float* obj, const float* img, const int64_t* view_ptr, const int32_t* slot_view,
                       const camcal_tiles* t, float* out, void*) {
   CC_OMP_FOR

@@ -70,3 +70,18 @@ def test_randomised_small_calls_one_call_path_equals_the_stage_loop():
                        capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0
+
+
+@pytest.mark.gpu
+def test_device_layout_equals_the_host_layout():
+    """camcal_layout_device (sort, prefix sums, planarity and offset checks on the device) writes the tables
+    camcal_layout / engine.make_layout write, element for element, ties included."""
+    import torch
+    from cameracalibration_amd import _lib
+    from tests.test_abi import check_device_layout
+    lib = _lib.load()
+    assert not lib.is_emulator
+    dev = torch.device("cuda:0")
+    to_dev = lambda a: torch.from_numpy(a).to(dev)
+    to_host = lambda t: (torch.cuda.synchronize(), t.cpu().numpy())[1]
+    check_device_layout(lib, to_dev, to_host, (0, 1, 63, 64, 65, 1000, 8191, 8192, 100000, 1000001))
