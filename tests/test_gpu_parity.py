@@ -542,4 +542,15 @@ def test_device_side_layout_equals_the_host_layout(dev):
     finally:
         Engine.DEVICE_LAYOUT_MIN_VIEWS = old
     assert F._layout is not None and torch.equal(E.t_pts, F.t_pts) and E.n_obs == F.n_obs
+    assert E.tiles.planar == 1 and F.tiles.planar == 1
+    # what the device-side checks report: offsets that do not fit the point arrays, a board off its plane
+    with pytest.raises(ValueError):
+        Engine(1, P.view_ptr, P.obj[:-1], P.img[:-1], dev)
+    bad = torch.as_tensor(P.view_ptr).clone()
+    bad[5] = bad[7]                                            # view 5 gets a negative count
+    with pytest.raises(ValueError):
+        Engine(1, bad, P.obj, P.img, dev)
+    off = P.obj.clone()
+    off[-1, 2] = 0.5
+    assert Engine(1, P.view_ptr, off, P.img, dev).tiles.planar == 0
 
