@@ -27,6 +27,9 @@ for name, model in (("C1", "pinhole"), ("C2", "fisheye")):
     a = med(lambda: fn(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit))
     b = med(lambda: fn(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit, _info={}))
     print("%s one-call median %.3f min %.3f ms | engine path median %.3f min %.3f ms" % (name, a[0], a[1], b[0], b[1]), flush=True)
+    so, si = np.stack(o), np.stack(i)                   # the views stacked in one array each: nothing to gather
+    c = med(lambda: fn(so, si, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=crit))
+    print("%s one-call, stacked arrays median %.3f min %.3f ms" % (name, c[0], c[1]), flush=True)
 
 calls = []
 for name, model, nv, seed in (("C3", "fisheye", 25, 31), ("C3", "fisheye", 25, 32), ("C1R", "pinhole", 25, 33), ("C1R", "pinhole", 25, 34)):
