@@ -72,6 +72,7 @@ _SIGNATURES = {
     "camcal_scratch_len": (C.c_int64, [_I, _I]),
     "camcal_layout": (C.c_int, [C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "camcal_layout_device_temp_len": (C.c_int64, [C.c_int64]),
+    "camcal_points_off_plane": (C.c_int, [C.c_int64, _P, _P, _P]),
     "camcal_layout_device": (C.c_int, [C.c_int64, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "camcal_pack_tiles": (C.c_int, [_P, _P, _P, _P, _TP, _P, _P]),
     "camcal_pose_init": (C.c_int, [_I, _TP, _P, _P, _P, _P]),

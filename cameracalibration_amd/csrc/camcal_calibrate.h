@@ -16,6 +16,9 @@
 // the includer provides, with internal linkage, besides what camcal_driver.h and
 // camcal_rig_driver.h ask for,
 //   int camcal_upload(void* dst_dev, const void* src_host, size_t bytes, void* stream)
+//   int camcal_upload_bulk(void* dst_dev, const void* src_host, size_t bytes, void* stream)
+//       (a large array: may stage it through page-locked memory on several threads; the host side is free again
+//        when it returns)
 //   int camcal_download(void* dst_host, const void* src_dev, size_t bytes, void* stream)
 //       (asynchronous, ordered on the stream; the host side must stay valid until the sync)
 //   int camcal_stream_sync(void* stream)
@@ -24,8 +27,10 @@
 //       (page-locked host staging from a pool that lives as long as the process; NULL: none to be had, the
 //        copies then go from / to the caller's arrays directly)
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -57,7 +62,7 @@ struct Carve {
   size_t pose0 = 0, status = 0, res_bytes = 0;
   size_t pts = 0;
   size_t intr1 = 0, pose1 = 0, V0 = 0, V1 = 0, g0 = 0, g1 = 0, W1 = 0, intr_spare = 0, W = 0, rec = 0, glob1 = 0, dK = 0, stats = 0,
-         scratch = 0, iters = 0;
+         scratch = 0, iters = 0, flag = 0;
   size_t total = 0;
 };
 
@@ -99,6 +104,7 @@ inline Carve carve(int model, int64_t n_views, int64_t n_obs, int32_t T, int64_t
     c.W1 = dbl((size_t)ni * 6 * S);    // spare cross blocks + intrinsics: the LM loop runs half a step ahead (camcal_driver.h)
     c.intr_spare = dbl(16);
   }
+  c.flag = dbl(4);                     // camcal_points_off_plane's four words (large sets)
   c.scratch = dbl((size_t)camcal_scratch_len(model, T));
   c.iters = o; o = up(o + (size_t)S * 4);
   c.total = o;
@@ -116,6 +122,37 @@ inline size_t pin_limit() {
   return v;
 }
 
+// CAMCAL_TRACE_SETUP (environment, read once): the host-side phases of a call's set-up with their wall clock, on stderr
+struct PhaseClock {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseClock() {
+    static const bool env = std::getenv("CAMCAL_TRACE_SETUP") != nullptr;
+    on = env;
+    if (on) t = std::chrono::steady_clock::now();
+  }
+  void lap(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[camcal set-up] %-28s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
+
+// From this many points on a single-rank call tests the planarity of its target on the device, behind the upload
+// (one pass at HBM speed, the verdict comes back with the results), instead of walking the host array first: at 1M
+// views x 88 corners the host pass costs 28 ms of a 138 ms call.  A multi-rank call keeps the host test: a shard
+// that fails must be known before the first collective (agree_on_setup).
+constexpr int64_t PLANAR_ON_DEVICE_MIN_OBS = (int64_t)1 << 20;
+// CAMCAL_PLANAR_ON_DEVICE_MIN (points, read once) overrides it (tests: 0 sends every single-rank call that way)
+inline int64_t planar_on_device_min() {
+  static const int64_t v = [] {
+    const char* e = std::getenv("CAMCAL_PLANAR_ON_DEVICE_MIN");
+    return e ? (int64_t)std::strtoll(e, nullptr, 10) : PLANAR_ON_DEVICE_MIN_OBS;
+  }();
+  return v;
+}
+
 struct Solve {
   camcal_problem* p = nullptr;
   const camcal_comm* comm = nullptr;
@@ -128,6 +165,8 @@ struct Solve {
   double intr0[16];
   void* pin = nullptr;                 // pinned staging for the one upload and the one download (or NULL: direct copies)
   bool collecting = false;             // the result copies are on the stream
+  bool planar_on_device = false;
+  int64_t planar_flag[4] = {0, 0, 0, 0};
   ~Solve() { if (pin) camcal_pinned_give(pin); }
   Carve c;
   camcal_tiles tiles{};
@@ -192,6 +231,7 @@ struct Solve {
   // everything up to the first step of the loop, enqueued on the stream
   int setup() {
     CAMCAL_DRV_TRY(check());
+    PhaseClock clk;
     const int64_t N = p->n_views;
     if (p->view_ptr[0] != 0) return CAMCAL_E_BADARG;
     std::vector<int32_t> n_per_view((size_t)N);
@@ -201,8 +241,12 @@ struct Solve {
       n_per_view[(size_t)v] = (int32_t)n;
     }
     n_obs = p->view_ptr[N];
-    for (int64_t i = 0; i < n_obs; ++i)
-      if (p->obj[i * 3 + 2] != 0.f) return CAMCAL_E_UNSUPPORTED;  // planar targets only (the reference's boards)
+    clk.lap("corner counts");
+    planar_on_device = !comm && n_obs >= planar_on_device_min();
+    if (!planar_on_device)
+      for (int64_t i = 0; i < n_obs; ++i)
+        if (p->obj[i * 3 + 2] != 0.f) return CAMCAL_E_UNSUPPORTED;  // planar targets only (the reference's boards)
+    clk.lap("planarity test");
     CAMCAL_DRV_TRY(camcal_layout(N, n_per_view.data(), &T, &S, &total_floats, nullptr, nullptr, nullptr, nullptr));
     c = carve(p->model, N, n_obs, T, S, total_floats);
     if ((int64_t)c.total > p->workspace_bytes) return CAMCAL_E_TOOBIG;
@@ -212,6 +256,7 @@ struct Solve {
                                  (int32_t*)(head.data() + c.lane_n), (int32_t*)(head.data() + c.tile_nmax),
                                  (int64_t*)(head.data() + c.tile_off)));
     std::memcpy(head.data() + c.view_ptr, p->view_ptr, (size_t)(N + 1) * 8);
+    clk.lap("layout (sizes, then tables)");
     const size_t pin_bytes = c.up_bytes > c.res_bytes ? c.up_bytes : c.res_bytes;
     if (pin_bytes <= pin_limit()) pin = camcal_pinned_take(pin_bytes);
     if (pin) {                                    // one block, one copy
@@ -223,10 +268,12 @@ struct Solve {
       CAMCAL_DRV_TRY(camcal_upload(ws(), u, c.up_bytes, stream));
     } else {
       CAMCAL_DRV_TRY(camcal_upload(ws(), head.data(), c.tables_bytes, stream));
-      CAMCAL_DRV_TRY(camcal_upload(ws() + c.img, p->img, (size_t)n_obs * 8, stream));
-      CAMCAL_DRV_TRY(camcal_upload(ws() + c.obj, p->obj, (size_t)n_obs * 12, stream));
+      CAMCAL_DRV_TRY(camcal_upload_bulk(ws() + c.img, p->img, (size_t)n_obs * 8, stream));
+      CAMCAL_DRV_TRY(camcal_upload_bulk(ws() + c.obj, p->obj, (size_t)n_obs * 12, stream));
       CAMCAL_DRV_TRY(camcal_upload(ws() + c.intr0, intr0, sizeof(intr0), stream));
     }
+    clk.lap("staging + upload calls");
+    if (planar_on_device) CAMCAL_DRV_TRY(camcal_points_off_plane(n_obs, at<float>(c.obj), at<int64_t>(c.flag), stream));
     tiles.pts = at<float>(c.pts);
     tiles.tile_off = at<int64_t>(c.tile_off);
     tiles.tile_nmax = at<int32_t>(c.tile_nmax);
@@ -312,21 +359,46 @@ struct Solve {
     r_intr = (const double*)dst;
     r_pose = (const double*)(dst + 128);
     r_status = (const int32_t*)(dst + 128 + pose_bytes);
+    if (planar_on_device) CAMCAL_DRV_TRY(camcal_download(planar_flag, ws() + c.flag, sizeof(planar_flag), stream));
     if (cur == 0) return camcal_download(dst, ws() + c.intr0, c.res_bytes, stream);     // one block
     CAMCAL_DRV_TRY(camcal_download(dst, ws() + c.intr1, 128 + pose_bytes, stream));
     return camcal_download(dst + 128 + pose_bytes, ws() + c.status, st_bytes, stream);
   }
   // ... and, after the stream has drained, hand them out in the caller's order
   int collect_end(int loop_rc) {
+    if (planar_on_device && planar_flag[2] != 0) return CAMCAL_E_UNSUPPORTED;   // planar targets only; nothing of this solve is handed out
     const int32_t* slot_view = (const int32_t*)(head.data() + c.slot_view);
-    int64_t n_bad = 0;
-    for (int64_t s = 0; s < S; ++s) {
-      const int32_t v = slot_view[s];
-      if (v < 0) continue;
-      for (int k = 0; k < 6; ++k) p->rt[(size_t)v * 6 + k] = r_pose[(size_t)k * S + s];
-      if (p->view_status) p->view_status[v] = r_status[(size_t)s];
-      n_bad += r_status[(size_t)s] != 0;
+    // slot order -> the caller's view order (every view sits in exactly one slot: the ranges write disjoint rows);
+    // a large set is split over a few threads (1M views: 6 ms of a single thread's loads and stores)
+    auto reorder = [&](int64_t s0, int64_t s1, int64_t* bad_out) {
+      int64_t bad = 0;
+      for (int64_t s = s0; s < s1; ++s) {
+        const int32_t v = slot_view[s];
+        if (v < 0) continue;
+        for (int k = 0; k < 6; ++k) p->rt[(size_t)v * 6 + k] = r_pose[(size_t)k * S + s];
+        if (p->view_status) p->view_status[v] = r_status[(size_t)s];
+        bad += r_status[(size_t)s] != 0;
+      }
+      *bad_out = bad;
+    };
+    constexpr int RT = 4;
+    int64_t bad_part[RT] = {0, 0, 0, 0};
+    if (S >= ((int64_t)1 << 16)) {
+      std::vector<std::thread> th;
+      const int64_t per = (S + RT - 1) / RT;
+      int started = 1;
+      try {
+        for (; started < RT; ++started)
+          th.emplace_back(reorder, started * per, (started + 1) * per < S ? (started + 1) * per : S, &bad_part[started]);
+      } catch (...) {
+      }
+      reorder(0, per < S ? per : S, &bad_part[0]);
+      for (int t = started; t < RT; ++t) reorder(t * per, (t + 1) * per < S ? (t + 1) * per : S, &bad_part[t]);
+      for (auto& x : th) x.join();
+    } else {
+      reorder(0, S, &bad_part[0]);
     }
+    const int64_t n_bad = bad_part[0] + bad_part[1] + bad_part[2] + bad_part[3];
     // totals over the ranks (multi-rank call): observations for the rms, degenerate views for a collective verdict
     double tot[2] = {(double)n_obs, (double)n_bad};
     if (comm) {

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "camcal_lane.h"
 #include "camcal_rig.h"
@@ -2565,6 +2566,83 @@ void camcal_pinned_give(void* p) {
     (void)hipHostFree(g_pin_free[k].p);
     g_pin_free.erase(g_pin_free.begin() + (long)k);
   }
+}
+// A large host array to the device through page-locked staging filled by several threads: the copy engine moves
+// pinned memory at 57 GB/s on this part, one thread fills staging at 10 - 15, and hipMemcpyAsync from the caller's
+// pageable array (one staging thread inside the runtime) reached 27 GB/s on the 1.77 GB of a 1M-view set.
+// Thread t takes chunks t, t + T, ... through two buffers of its own: fill, enqueue the copy on `stream`, record an
+// event, and wait for that event before the buffer is filled again.  Returns after the last copy has finished (the
+// buffers go back to the pool); small arrays, or no staging to be had: the plain copy.
+constexpr size_t BULK_CHUNK_DEFAULT = (size_t)8 << 20;
+constexpr int BULK_THREADS = 4, BULK_BUFS = 2;
+int camcal_upload_bulk(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+  // CAMCAL_BULK_CHUNK (bytes, read once): the chunk size (tests: a few KB send small arrays this way too)
+  static const size_t BULK_CHUNK = [] {
+    const char* e = std::getenv("CAMCAL_BULK_CHUNK");
+    const size_t v = e ? (size_t)std::strtoull(e, nullptr, 10) : 0;
+    return v >= 256 ? v : BULK_CHUNK_DEFAULT;
+  }();
+  if (bytes < 4 * BULK_CHUNK) return camcal_upload(dst_dev, src_host, bytes, stream);
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  void* buf[BULK_THREADS][BULK_BUFS] = {};
+  hipEvent_t ev[BULK_THREADS][BULK_BUFS] = {};
+  bool ok = true;
+  for (int t = 0; t < BULK_THREADS && ok; ++t)
+    for (int b = 0; b < BULK_BUFS && ok; ++b) {
+      buf[t][b] = camcal_pinned_take(BULK_CHUNK);
+      ok = buf[t][b] != nullptr && hipEventCreateWithFlags(&ev[t][b], hipEventDisableTiming) == hipSuccess;
+    }
+  auto release = [&]() {
+    for (int t = 0; t < BULK_THREADS; ++t)
+      for (int b = 0; b < BULK_BUFS; ++b) {
+        if (ev[t][b]) (void)hipEventDestroy(ev[t][b]);
+        if (buf[t][b]) camcal_pinned_give(buf[t][b]);
+      }
+  };
+  if (!ok) {
+    (void)hipGetLastError();
+    release();
+    return camcal_upload(dst_dev, src_host, bytes, stream);
+  }
+  const size_t n_chunks = (bytes + BULK_CHUNK - 1) / BULK_CHUNK;
+  int err[BULK_THREADS] = {};
+  auto work = [&](int t, bool own_thread) {
+    if (own_thread && hipSetDevice(dev) != hipSuccess) { err[t] = (int)hipErrorInvalidDevice; return; }
+    int k = 0;
+    for (size_t c = (size_t)t; c < n_chunks; c += BULK_THREADS, ++k) {
+      const int b = k % BULK_BUFS;
+      hipError_t e = k >= BULK_BUFS ? hipEventSynchronize(ev[t][b]) : hipSuccess;    // its last copy has left the buffer
+      const size_t off = c * BULK_CHUNK, len = bytes - off < BULK_CHUNK ? bytes - off : BULK_CHUNK;
+      if (e == hipSuccess) {
+        std::memcpy(buf[t][b], (const char*)src_host + off, len);
+        e = hipMemcpyAsync((char*)dst_dev + off, buf[t][b], len, hipMemcpyHostToDevice, (hipStream_t)stream);
+      }
+      if (e == hipSuccess) e = hipEventRecord(ev[t][b], (hipStream_t)stream);
+      if (e != hipSuccess) { err[t] = (int)e; return; }
+    }
+    for (int b = 0; b < BULK_BUFS && b < k; ++b) {                                     // drain: the buffers are handed back
+      const hipError_t e = hipEventSynchronize(ev[t][b]);
+      if (e != hipSuccess) { err[t] = (int)e; return; }
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    int started = 1;
+    try {
+      for (; started < BULK_THREADS; ++started) th.emplace_back(work, started, true);
+    } catch (...) {
+    }
+    work(0, false);
+    for (int t = started; t < BULK_THREADS; ++t) work(t, false);
+    for (auto& x : th) x.join();
+  }
+  int rc = 0;
+  for (int t = 0; t < BULK_THREADS; ++t)
+    if (err[t] && !rc) rc = err[t];
+  if (rc) (void)hipStreamSynchronize((hipStream_t)stream);     // nothing may still read a buffer that goes back to the pool
+  release();
+  return rc;
 }
 int camcal_get_device(int* dev) {
   HIP_TRY(hipGetDevice(dev));

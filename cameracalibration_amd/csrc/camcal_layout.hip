@@ -159,4 +159,17 @@ int camcal_layout_device(int64_t n_views, const int64_t* view_ptr, int64_t n_obs
   return 0;
 }
 
+
+int camcal_points_off_plane(int64_t n_obs, const float* obj_xyz, int64_t* flag, void* stream) {
+  if (n_obs < 0 || !flag || (n_obs > 0 && !obj_xyz)) return CAMCAL_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4 * sizeof(int64_t), s));
+  if (n_obs == 0) return 0;
+  const int64_t nb = (n_obs + LTPB - 1) / LTPB;
+  hipLaunchKernelGGL(k_layout_planar, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(LTPB), 0, s, n_obs, obj_xyz,
+                     (unsigned long long*)flag);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -123,6 +123,12 @@ int camcal_layout_device(int64_t n_views, const int64_t* view_ptr, int64_t n_obs
                          int32_t* slot_view, int32_t* lane_n, int32_t* tile_nmax, int64_t* tile_off,
                          int64_t* head, void* temp, int64_t temp_bytes, void* stream);
 
+/* The planarity test of camcal_layout_device on its own: flag = 4 x i64 in DEVICE memory (the layout's head:
+ * flag[2] = CAMCAL_LAYOUT_NOT_PLANAR if some Z of obj_xyz [n_obs][3] f32 (device) is not 0, else 0; flag[0], [1],
+ * [3] are cleared).  Stream-ordered, no allocation.  camcal_calibrate uses it for sets of a million points and
+ * more, where the same test over the host array costs more than the upload it precedes. */
+int camcal_points_off_plane(int64_t n_obs, const float* obj_xyz, int64_t* flag, void* stream);
+
 /* Gather cv2-style AoS points into tiles.  obj_xyz [n_obs][3] f32, img_uv
  * [n_obs][2] f32, view_ptr [n_views+1] i64 (CSR), slot_view [n_slots] i32 =
  * view index placed in each slot or -1.  Writes tiles->pts (caller-allocated,
@@ -449,7 +455,11 @@ int64_t camcal_workspace_len(int model, int64_t n_views, const int64_t* view_ptr
  * rank receives the same K, D and the poses of its own views; a shard that is rejected (bad
  * arguments, workspace too small) or a degenerate view on any rank fails the call on every rank
  * (its own code where it happened, CAMCAL_E_PEER elsewhere) -- provided every rank passes at
- * least 256 bytes of aligned device workspace to exchange that verdict through. */
+ * least 256 bytes of aligned device workspace to exchange that verdict through.
+ * Large sets (single rank): from 2^20 points on the planarity of the target is tested on the device behind the
+ * upload, so CAMCAL_E_UNSUPPORTED for a non-planar target is returned at the end of the call (nothing is handed
+ * out) rather than before any device work; host arrays of 32 MB and more are uploaded through page-locked
+ * staging filled by a few threads of the library's own. */
 int camcal_calibrate(int model, int64_t n_views, const int64_t* view_ptr_host, const float* obj_host,
                      const float* img_host, int width, int height, double* K_host, double* D_host,
                      int n_dist, double* rt_host, int32_t* view_status_host, int flags, int crit_type,

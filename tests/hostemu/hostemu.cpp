@@ -414,6 +414,14 @@ int camcal_layout_device(int64_t n_views, const int64_t* view_ptr, int64_t n_obs
   return 0;
 }
 
+int camcal_points_off_plane(int64_t n_obs, const float* obj_xyz, int64_t* flag, void*) {
+  if (n_obs < 0 || !flag || (n_obs > 0 && !obj_xyz)) return CAMCAL_E_BADARG;
+  flag[0] = flag[1] = flag[2] = flag[3] = 0;
+  for (int64_t i = 0; i < n_obs; ++i)
+    if (!(obj_xyz[3 * i + 2] == 0.0f)) { flag[2] = CAMCAL_LAYOUT_NOT_PLANAR; break; }
+  return 0;
+}
+
 int camcal_pack_tiles(const float* obj, const float* img, const int64_t* view_ptr, const int32_t* slot_view,
                       const camcal_tiles* t, float* out, void*) {
   CC_OMP_FOR
@@ -913,6 +921,7 @@ int camcal_fork_streams(void* stream, int n, void** side_out) {   // no streams 
 }
 int camcal_join_streams(void*, int, void**) { return 0; }
 int camcal_upload(void* dst, const void* src_host, size_t bytes, void*) { std::memcpy(dst, src_host, bytes); return 0; }
+int camcal_upload_bulk(void* dst, const void* src_host, size_t bytes, void*) { std::memcpy(dst, src_host, bytes); return 0; }
 int camcal_download(void* dst_host, const void* src, size_t bytes, void*) { std::memcpy(dst_host, src, bytes); return 0; }
 int camcal_stream_sync(void*) { return 0; }
 void* camcal_pinned_take(size_t bytes) { return std::malloc(bytes ? bytes : 1); }

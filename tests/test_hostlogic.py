@@ -371,3 +371,45 @@ def test_static_entry_rejection_codes_match_the_hip_build(emu):
         assert call(1, tiles(16385, 0, planar=0)) == -3
         assert call(1, tiles(20000, 64)) == -3           # too many tiles for 64 lanes per view: one lane per view, 20000 records
     # (a grouped set never exceeds the limit: 32 tiles x 64 lanes = 2048, 448 tiles x 16 lanes = 7168 partial records)
+
+
+_PLANAR_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import cameracalibration_amd as cc
+from cameracalibration_amd import synth, _lib
+from tests.conftest import use_emulator, EMU_PATH
+use_emulator(_lib.load(EMU_PATH))
+out = []
+for name, fn, fl in (("C2", cc.fisheye.calibrate, 8 | 2 | 1), ("C1", cc.calibrateCamera, 1)):
+    P = synth.config(name, n_views=12)
+    o, i = P.as_lists()
+    r = fn(o, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=(3, 30, 1e-6))
+    out.append(np.concatenate([[r[0]], r[1].ravel(), np.asarray(r[2]).ravel(), np.hstack(r[3]).ravel()]))
+    off = [x.copy() for x in o]
+    off[3][5, 0, 2] = 1.0
+    try:
+        fn(off, i, P.image_size, P.K_guess.copy(), P.D_guess.copy(), flags=fl, criteria=(3, 30, 1e-6))
+        raise SystemExit("a non-planar target was accepted")
+    except cc.error as e:
+        assert "planar" in str(e).lower(), str(e)
+np.save(sys.argv[1], np.concatenate(out))
+"""
+
+
+def test_planarity_verdict_from_the_device_side_test(tmp_path):
+    """camcal_calibrate with the target's planarity tested behind the upload (the path of sets of a million
+    points and more, forced here by CAMCAL_PLANAR_ON_DEVICE_MIN=0) on the emulator: same results as with the host
+    test, and a board with a corner off its plane is refused just the same."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("host", {}), ("device", {"CAMCAL_PLANAR_ON_DEVICE_MIN": "0"})):
+        f = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", _PLANAR_SCRIPT % ROOT, f], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(f)
+    assert np.array_equal(res["host"], res["device"])
