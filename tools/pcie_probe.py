@@ -1,3 +1,5 @@
+"""Copy rates of the box: 1 GiB host -> device and back from pinned and from pageable memory, and the host's own
+pageable -> pinned memcpy (what bounds a staged upload).  Behind camcal_upload_bulk's design."""
 import torch, time
 dev = torch.device("cuda:0")
 n = 1 << 30
