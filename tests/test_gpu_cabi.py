@@ -57,19 +57,20 @@ def test_one_call_entry_on_its_fallback_transfer_paths(tmp_path):
     the same results to the bit as the default paths -- only the transfers differ.  Likewise with the planarity test
     of the target moved onto the device (CAMCAL_PLANAR_ON_DEVICE_MIN=0: what sets of a million points and more do);
     and with the point arrays uploaded the way large ones are (several threads through page-locked staging; forced here by
-    a 1 KB chunk); every variant refuses a board with one corner off its plane."""
+    a 1 KB chunk; and started before the host lays the views out, CAMCAL_EARLY_UPLOAD_MIN=0); every variant refuses a board with one corner off its plane."""
     import numpy as np
     res = {}
     for tag, env in (("default", {}), ("direct", {"CAMCAL_PIN_LIMIT": "0"}), ("copies", {"CAMCAL_NO_NOTIFY": "1"}),
                      ("both", {"CAMCAL_PIN_LIMIT": "0", "CAMCAL_NO_NOTIFY": "1"}),
                      ("planarity on the device", {"CAMCAL_PLANAR_ON_DEVICE_MIN": "0"}),
-                     ("threaded upload", {"CAMCAL_PIN_LIMIT": "0", "CAMCAL_BULK_CHUNK": "1024"})):
+                     ("threaded upload", {"CAMCAL_PIN_LIMIT": "0", "CAMCAL_BULK_CHUNK": "1024"}),
+                     ("early threaded upload", {"CAMCAL_PIN_LIMIT": "0", "CAMCAL_BULK_CHUNK": "1024", "CAMCAL_EARLY_UPLOAD_MIN": "0"})):
         f = str(tmp_path / (tag + ".npy"))
         r = subprocess.run([os.sys.executable, "-c", _FALLBACK_SCRIPT % ROOT, f], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = np.load(f)
-    for tag in ("direct", "copies", "both", "planarity on the device", "threaded upload"):
+    for tag in ("direct", "copies", "both", "planarity on the device", "threaded upload", "early threaded upload"):
         assert np.array_equal(res[tag], res["default"]), tag
 
 

@@ -406,10 +406,11 @@ def test_planarity_verdict_from_the_device_side_test(tmp_path):
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, env in (("host", {}), ("device", {"CAMCAL_PLANAR_ON_DEVICE_MIN": "0"})):
+    for tag, env in (("host", {}), ("device", {"CAMCAL_PLANAR_ON_DEVICE_MIN": "0"}),
+                     ("early", {"CAMCAL_PIN_LIMIT": "0", "CAMCAL_EARLY_UPLOAD_MIN": "0"})):      # the large calls' upload thread
         f = str(tmp_path / (tag + ".npy"))
         r = subprocess.run([sys.executable, "-c", _PLANAR_SCRIPT % ROOT, f], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = np.load(f)
-    assert np.array_equal(res["host"], res["device"])
+    assert np.array_equal(res["host"], res["device"]) and np.array_equal(res["host"], res["early"])
