@@ -421,6 +421,7 @@ struct Solve {
   // ... and, after the stream has drained, hand them out in the caller's order
   int collect_end(int loop_rc) {
     if (planar_on_device && planar_flag[2] != 0) return CAMCAL_E_UNSUPPORTED;   // planar targets only; nothing of this solve is handed out
+    PhaseClock clk_end;
     const int32_t* slot_view = (const int32_t*)(head.data() + c.slot_view);
     // slot order -> the caller's view order (every view sits in exactly one slot: the ranges write disjoint rows);
     // a large set is split over a few threads (1M views: 6 ms of a single thread's loads and stores)
@@ -453,6 +454,7 @@ struct Solve {
       reorder(0, S, &bad_part[0]);
     }
     const int64_t n_bad = bad_part[0] + bad_part[1] + bad_part[2] + bad_part[3];
+    clk_end.lap("view order");
     // totals over the ranks (multi-rank call): observations for the rms, degenerate views for a collective verdict
     double tot[2] = {(double)n_obs, (double)n_bad};
     if (comm) {
@@ -488,6 +490,7 @@ inline void fail(camcal_problem* p, int rc) {
 // read-back, drained stream.  rc: the solve's own status; the return value: whether the read-back worked
 inline int run_to_readback(Solve& s) {
   s.rc = s.agree_on_setup(s.setup());
+  PhaseClock clk;
   if (s.rc == 0) {
     while (!s.done()) {
       int rc = s.launch();
@@ -498,8 +501,10 @@ inline int run_to_readback(Solve& s) {
     }
   }
   if (!(s.gn || s.lm) || s.rc == CAMCAL_E_PEER) return 0;   // rejected before any device work / with the other ranks
+  clk.lap("loop (host side)");
   int rc = s.collect_begin();                  // got as far as the device: read back what there is
   if (rc == 0) rc = camcal_stream_sync(s.stream);
+  clk.lap("results on the host");
   return rc;
 }
 
