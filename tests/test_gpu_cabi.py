@@ -86,6 +86,18 @@ def test_randomised_small_calls_one_call_path_equals_the_stage_loop():
 
 
 @pytest.mark.gpu
+def test_randomised_mid_size_calls_grouped_kernels_equal_the_large_set_kernels():
+    """tools/gpu_fuzz_mid.py: 16 random sets of 1500 ... 40 000 views (both models, full and ragged boards) through the
+    one-call entry from host arrays (host layout; 64 / 16 lanes per view or one, folded or separate stages, by size)
+    against the engine solve forced to one lane per view (the large-set kernels; device layout from 8192 views on):
+    equal iteration counts, rms to 1e-9, K to 1e-8, poses to 1e-6 (measured: round-off, 1e-13)."""
+    r = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz_mid.py"), "7", "16"],
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0
+
+
+@pytest.mark.gpu
 def test_device_layout_equals_the_host_layout():
     """camcal_layout_device (sort, prefix sums, planarity and offset checks on the device) writes the tables
     camcal_layout / engine.make_layout write, element for element, ties included."""
